@@ -1,0 +1,93 @@
+"""ctypes binding of libcugs_hip.so (the C ABI declared in include/cugs_hip.h).
+
+The HIP library is the product.  There is no CPU or PyTorch fallback: if the shared
+object is missing or does not export a declared symbol, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcugs_hip.so")
+
+PACKED_STRIDE = 12   # CUGS_PACKED_STRIDE
+GRAD_STRIDE = 16     # CUGS_GRAD_STRIDE
+TILE = 16            # CUGS_TILE
+
+
+class Camera(C.Structure):
+    """struct cugs_camera."""
+    _fields_ = [("view", C.c_float * 16), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
+                ("cam_center", C.c_float * 3), ("reserved", C.c_float)]
+
+
+class AdamGroup(C.Structure):
+    """struct cugs_adam_group."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("reserved", C.c_float)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+
+# name -> (restype, argtypes); must list every function of include/cugs_hip.h
+SIGNATURES = {
+    "cugs_version": (C.c_char_p, []),
+    "cugs_error_string": (C.c_char_p, [_I]),
+    "cugs_project_forward": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, C.POINTER(Camera), _F,
+                                  _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cugs_evaluate_sh": (_I, [_I, _L, _I, _P, _P, _P, _P]),
+    "cugs_evaluate_sh_backward": (_I, [_I, _L, _I, _P, _P, _P, _P, _P]),
+    "cugs_pack_projected": (_I, [_L, _P, _P, _P, _P, _P, _P]),
+    "cugs_sort_workspace_bytes": (C.c_size_t, [_L, _L, _I, _I]),
+    "cugs_sort_count_pairs": (_I, [_L, _P, _P, C.c_size_t, C.POINTER(C.c_int64), _P]),
+    "cugs_sort_pairs": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, _P, _P, _P]),
+    "cugs_rasterize_forward": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
+                                    _P, _P, _P, _P]),
+    "cugs_rasterize_backward": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
+    "cugs_project_backward": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Camera), _F,
+                                   _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cugs_adam_bias_correction": (None, [_F, _F, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cugs_fused_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
+    "cugs_fused_adam_groups": (_I, [C.POINTER(AdamGroup), _I, _F, _F, _F, _F, _F, _P]),
+    "cugs_device_count": (_I, [C.POINTER(C.c_int)]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no fallback path: the HIP library is the implementation.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise ImportError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class CugsError(RuntimeError):
+    """Non-zero return from the C ABI (the adapter's std::runtime_error, cuda_utils.cuh:12-20)."""
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib.cugs_error_string(int(code)).decode()
+        raise CugsError(f"{what} failed with code {code}: {msg}")
+
+
+def version() -> str:
+    return lib.cugs_version().decode()

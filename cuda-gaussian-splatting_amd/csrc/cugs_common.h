@@ -1,0 +1,55 @@
+// cugs_common.h — shared declarations for the gfx950 kernels behind include/cugs_hip.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/Makefile).  Contraction
+// is OFF for the whole library: the only fused multiply-adds are explicit fmaf calls, placed
+// where DESIGN.md's "FMA placement contract" says, so that integer outputs and blend decisions
+// are bit-identical to the CPU oracle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cugs_hip.h"
+#include "../../include/cugs_detmath.h"
+
+#define CUGS_BLOCK 256
+#define CUGS_WAVE 64
+
+// Launch-error convention of the reference (CUDA_CHECK(cudaGetLastError()), projection.cu:267):
+// report launch errors only, never synchronise.
+#define CUGS_RETURN_IF_HIP(expr)                    \
+    do {                                            \
+        hipError_t _e = (expr);                     \
+        if (_e != hipSuccess) return (int)_e;       \
+    } while (0)
+
+#define CUGS_LAUNCH_CHECK() CUGS_RETURN_IF_HIP(hipGetLastError())
+
+static inline bool cugs_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Camera as kernel argument (passed by value: no per-call H2D copy, unlike projection.cu:236,274).
+struct CamArgs {
+    float view[16];
+    float fx, fy, cx, cy;
+    int width, height;
+    float cc[3];
+    float log_mod;      // logf(scale_modifier + 1e-8f), projection.cu:127
+};
+
+static inline CamArgs cugs_make_cam_args(const cugs_camera* c, float scale_modifier) {
+    CamArgs a;
+    for (int i = 0; i < 16; ++i) a.view[i] = c->view[i];
+    a.fx = c->fx; a.fy = c->fy; a.cx = c->cx; a.cy = c->cy;
+    a.width = c->width; a.height = c->height;
+    a.cc[0] = c->cam_center[0]; a.cc[1] = c->cam_center[1]; a.cc[2] = c->cam_center[2];
+    a.log_mod = logf(scale_modifier + 1e-8f);
+    return a;
+}
+
+// XCD-aware bijective block remap (cdna_hip_programming.md T1): blocks b and b+8 share an XCD,
+// so give each XCD a contiguous run of work items (neighbouring tiles share Gaussians -> L2 hits).
+__device__ __forceinline__ unsigned cugs_xcd_remap(unsigned bid, unsigned nwg) {
+    unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    unsigned base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

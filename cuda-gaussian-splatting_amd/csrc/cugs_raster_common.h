@@ -1,0 +1,129 @@
+// cugs_raster_common.h — pieces shared by the forward and backward blend kernels.
+//
+// Work decomposition (gfx950): one 256-thread workgroup per 16x16 tile = 4 wave64s, each wave
+// owning one 8x8 pixel QUAD of the tile (lane -> (lane&7, lane>>3)).  The tile's depth-sorted
+// Gaussian list is consumed in batches of 256 records staged in LDS (one record per thread,
+// three 16-byte gathers from the packed table).  Within a batch every wave first tests 64
+// records at a time, one record per lane, against its own quad (`may_touch_quad`, below), turns
+// the result into a 64-bit ballot mask, and then walks only the set bits: the per-pixel
+// evaluation runs for the (wave, Gaussian) pairs that can matter instead of all P x 256.
+//
+// The cull is CONSERVATIVE and therefore invisible in the results: a record is dropped for a wave
+// only when alpha < 1/255 is certain for all 64 pixel centres, with a margin that covers the
+// fp32 rounding of the per-pixel power (see the derivation at may_touch_quad).  The per-pixel
+// path itself (pixel_alpha) follows DESIGN.md's FMA placement contract and cugs_detmath.h, so
+// every skip / clamp / termination decision equals the oracle's bit for bit.
+#pragma once
+
+#include "cugs_gaussian_math.h"
+
+#define CUGS_REC_F4 3      // float4s per LDS record (CUGS_PACKED_STRIDE / 4)
+
+struct RasterGeom {
+    int width, height, ntx, ntiles;
+    float bg0, bg1, bg2;
+};
+
+struct RasterSrc {
+    const int32_t* tile_ranges;
+    const int32_t* gidx;
+    const float* packed;        // may be NULL -> gather from the four arrays below
+    const float* means_2d;
+    const float* cov_2d_inv;
+    const float* rgb;
+    const float* opa;
+};
+
+// Stage list entry `li` (if < end) into LDS slot threadIdx.x.  Returns the Gaussian index (or -1).
+template <bool PACKED>
+__device__ __forceinline__ int stage_record(const RasterSrc& s, int li, int end, float4* s_rec) {
+    if (li >= end) return -1;
+    const int g = s.gidx[li];
+    float4 r0, r1, r2;
+    if (PACKED) {
+        const float4* src = reinterpret_cast<const float4*>(s.packed + (int64_t)g * CUGS_PACKED_STRIDE);
+        r0 = src[0]; r1 = src[1]; r2 = src[2];
+    } else {
+        const float a = s.cov_2d_inv[g * 3 + 0], c = s.cov_2d_inv[g * 3 + 2], o = s.opa[g];
+        r0 = make_float4(s.means_2d[g * 2 + 0], s.means_2d[g * 2 + 1], a, s.cov_2d_inv[g * 3 + 1]);
+        r1 = make_float4(c, s.rgb[g * 3 + 0], s.rgb[g * 3 + 1], s.rgb[g * 3 + 2]);
+        r2 = make_float4(o, (o >= (1.0f / 255.0f)) ? logf(255.0f * o) : -1.0f,
+                         a > 0.0f ? 1.0f / a : 0.0f, c > 0.0f ? 1.0f / c : 0.0f);
+    }
+    s_rec[threadIdx.x * CUGS_REC_F4 + 0] = r0;
+    s_rec[threadIdx.x * CUGS_REC_F4 + 1] = r1;
+    s_rec[threadIdx.x * CUGS_REC_F4 + 2] = r2;
+    return g;
+}
+
+// Can the Gaussian in (r0, r1, r2) reach alpha >= 1/255 at ANY pixel centre of the 8x8 quad whose
+// first centre is (qx0, qy0)?  `false` only when certainly not.
+//
+// alpha = min(0.99, o * exp(power)) >= 1/255 needs -power <= tau := ln(255 o)  (tau < 0: never;
+// the record stores tau = -1 for o < 1/255, where o * exp(power <= 0) <= o < 1/255 exactly).
+// -power = q/2 with q(d) = a dx^2 + 2 b dx dy + c dy^2, d = centre - mean.  Over the rectangle of
+// quad offsets the minimum of q is 0 if the mean lies inside, else it is attained on an edge;
+// along each edge q is a 1-D convex parabola (a, c > 0), minimised at the clamped vertex.
+// Rounding: the oracle's fp32 power differs from the exact one by at most ~4 ulp of
+// B = |a| X^2 + 2 |b| X Y + |c| Y^2 (X, Y the largest |offset|); q_min here carries a similar
+// error; ocml logf ~2 ulp; detexp 1 ulp.  The slack 0.01 tau + 0.05 + 4e-6 B dominates all of it
+// by orders of magnitude.  Any NaN makes the final comparison false -> not culled.
+__device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float4 r2, float qx0, float qy0) {
+    const float mx = r0.x, my = r0.y, a = r0.z, b = r0.w, c = r1.x;
+    const float tau = r2.y, ia = r2.z, ic = r2.w;
+    if (!(tau >= 0.0f)) return false;
+    if (!(a > 0.0f && c > 0.0f)) return true;
+    const float lx = qx0 - mx, hx = lx + 7.0f, ly = qy0 - my, hy = ly + 7.0f;
+    const bool inside = (lx <= 0.0f) && (hx >= 0.0f) && (ly <= 0.0f) && (hy >= 0.0f);
+    const float X = fmaxf(fabsf(lx), fabsf(hx)), Y = fmaxf(fabsf(ly), fabsf(hy));
+    const float B = a * X * X + 2.0f * fabsf(b) * X * Y + c * Y * Y;
+    const float b2 = b + b;
+    // q restricted to the four edges, each at its clamped 1-D minimiser
+    const float y1 = fminf(fmaxf(-b * lx * ic, ly), hy);
+    const float y2 = fminf(fmaxf(-b * hx * ic, ly), hy);
+    const float x3 = fminf(fmaxf(-b * ly * ia, lx), hx);
+    const float x4 = fminf(fmaxf(-b * hy * ia, lx), hx);
+    const float q1 = a * lx * lx + b2 * lx * y1 + c * y1 * y1;
+    const float q2 = a * hx * hx + b2 * hx * y2 + c * y2 * y2;
+    const float q3 = a * x3 * x3 + b2 * x3 * ly + c * ly * ly;
+    const float q4 = a * x4 * x4 + b2 * x4 * hy + c * hy * hy;
+    const float qmin = inside ? 0.0f : fminf(fminf(q1, q2), fminf(q3, q4));
+    return !(0.5f * qmin > tau * 1.01f + 0.05f + 4e-6f * B);
+}
+
+// forward.cu:124-141 / backward.cu:123-137 for one pixel.  FMA placement contract:
+//   u = fma(a,dx,b*dy); v = fma(b,dx,c*dy); q = fma(dx,u,dy*v); power = -0.5f*q.
+// power < -5.6 can be dropped before the exponential: exp(-5.6)(1+2^-22) = 0.0036979 and
+// opacity <= 1, so alpha < 1/255 = 0.0039216 is certain (the oracle reaches the same skip
+// through its alpha test).  Returns false when the Gaussian is skipped at this pixel.
+struct PixelEval { float dx, dy, power, e, alpha; };
+__device__ __forceinline__ bool pixel_alpha(float pxf, float pyf, float mx, float my, float a, float b,
+                                            float c, float o, PixelEval& r) {
+    r.dx = pxf - mx;
+    r.dy = pyf - my;
+    const float u = fmaf(a, r.dx, b * r.dy);
+    const float v = fmaf(b, r.dx, c * r.dy);
+    const float q = fmaf(r.dx, u, r.dy * v);
+    r.power = -0.5f * q;
+    if (r.power > 0.0f || r.power < -5.6f) return false;
+    r.e = cugs_expf_core(r.power);
+    r.alpha = fminf(o * r.e, 0.99f);
+    return !(r.alpha < (1.0f / 255.0f));
+}
+
+// Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic).  After the call
+// lanes 48..63 hold the total; other lanes hold partial sums.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+    return v + __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float wave_sum_to_row3(float v) {
+    v = dpp_add<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]   : + lane^1
+    v = dpp_add<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]   : + lane^2   (quad sums everywhere)
+    v = dpp_add<0x141, 0xF>(v);    // row_half_mirror       : 8-lane sums everywhere
+    v = dpp_add<0x140, 0xF>(v);    // row_mirror            : 16-lane row sums everywhere
+    v = dpp_add<0x142, 0xA>(v);    // row_bcast:15 -> rows 1,3: row1 = r0+r1, row3 = r2+r3
+    v = dpp_add<0x143, 0xC>(v);    // row_bcast:31 -> rows 2,3: row3 = r0+r1+r2+r3
+    return v;
+}

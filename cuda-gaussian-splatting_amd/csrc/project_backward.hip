@@ -1,0 +1,431 @@
+// project_backward.hip — per-Gaussian chain rule from 2-D gradients to (p, q, log s, logit o) fused
+// with the SH colour backward (SURVEY §8 a8+a9).
+//
+// Replaces, in ONE launch: k_project_backward (rasterizer/projection_backward.cu:26-247), the
+// recomputed view directions (projection_backward.cu:332-338), k_evaluate_sh_backward
+// (core/sh_backward.cu:29-112) and five zero-fills (projection_backward.cu:275-278, sh_backward.cu:138).
+// Also provides the standalone evaluate_sh_backward_cuda surface (sh_backward.cu:114-156).
+//
+// gfx950 mapping: one thread per Gaussian.  The [n,3,C] gradient rows (the largest write of the
+// whole backward, 12C B/Gaussian) are assembled per thread in LDS (odd dword row stride) and
+// leave the workgroup as contiguous 16-byte stores.  With the forward's clamped rgb available
+// the ReLU gate needs no re-read of the coefficients (raw > 0 <=> clamped > 0, sh_backward.cu:92-100),
+// which removes 12C B/Gaussian of reads.  Bound: HBM; algorithmic bytes 44+4+64(+12) read,
+// 44+12C(+8) written per Gaussian.
+#include "cugs_gaussian_math.h"
+
+namespace {
+
+template <int C>
+struct ShTile {
+    static constexpr int ROW = 3 * C;
+    static constexpr int LROW = (ROW % 2 == 0) ? ROW + 1 : ROW;
+};
+
+template <int C, bool ALIGNED>
+__device__ __forceinline__ void load_sh_rows(const float* __restrict__ sh, int64_t base, int count, float* s_sh) {
+    constexpr int ROW = ShTile<C>::ROW, LROW = ShTile<C>::LROW;
+    const float* src = sh + base * ROW;
+    const int total = count * ROW;
+    if (ALIGNED) {
+        const int total4 = total >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        for (int e4 = threadIdx.x; e4 < total4; e4 += CUGS_BLOCK) {
+            const float4 v = src4[e4];
+            int e = e4 * 4, row = e / ROW, col = e - row * ROW;
+            const float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_sh[row * LROW + col] = vals[k];
+                if (++col == ROW) { col = 0; ++row; }
+            }
+        }
+        for (int e = (total4 << 2) + threadIdx.x; e < total; e += CUGS_BLOCK) {
+            int row = e / ROW, col = e - row * ROW;
+            s_sh[row * LROW + col] = src[e];
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += CUGS_BLOCK) {
+            int row = e / ROW, col = e - row * ROW;
+            s_sh[row * LROW + col] = src[e];
+        }
+    }
+}
+
+template <int C, bool ALIGNED>
+__device__ __forceinline__ void store_sh_rows(float* __restrict__ dst_base, int64_t base, int count,
+                                              const float* s_sh) {
+    constexpr int ROW = ShTile<C>::ROW, LROW = ShTile<C>::LROW;
+    float* dst = dst_base + base * ROW;
+    const int total = count * ROW;
+    if (ALIGNED) {
+        const int total4 = total >> 2;
+        float4* dst4 = reinterpret_cast<float4*>(dst);
+        for (int e4 = threadIdx.x; e4 < total4; e4 += CUGS_BLOCK) {
+            int e = e4 * 4, row = e / ROW, col = e - row * ROW;
+            float vals[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vals[k] = s_sh[row * LROW + col];
+                if (++col == ROW) { col = 0; ++row; }
+            }
+            dst4[e4] = make_float4(vals[0], vals[1], vals[2], vals[3]);
+        }
+        for (int e = (total4 << 2) + threadIdx.x; e < total; e += CUGS_BLOCK) {
+            int row = e / ROW, col = e - row * ROW;
+            dst[e] = s_sh[row * LROW + col];
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += CUGS_BLOCK) {
+            int row = e / ROW, col = e - row * ROW;
+            dst[e] = s_sh[row * LROW + col];
+        }
+    }
+}
+
+__device__ __forceinline__ int active_count(int degree) { return (degree + 1) * (degree + 1); }
+
+// raw colour as the backward recomputes it (sh_backward.cu:92-96: sum of c_k * Y_k, then + 0.5)
+__device__ __forceinline__ float raw_colour(const float* c, const float (&Y)[16], int num_active) {
+    float raw = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < num_active) raw += c[k] * Y[k];
+    return raw + 0.5f;
+}
+
+// dL/dSigma' from dL/dSigma'^-1 (backward.cuh:37-64): -S^-1 G S^-1 with the incoming
+// off-diagonal halved (Q3).
+__device__ __forceinline__ Sym2 grad_cov_from_inv(const Sym2& inv, const Sym2& g_inv) {
+    const float a = inv.a, b = inv.b, c = inv.c;
+    const float da = g_inv.a, db = g_inv.b * 0.5f, dc = g_inv.c;
+    const float t00 = a * da + b * db, t01 = a * db + b * dc;
+    const float t10 = b * da + c * db, t11 = b * db + c * dc;
+    return Sym2{-(t00 * a + t01 * b), -(t00 * b + t01 * c), -(t10 * b + t11 * c)};
+}
+
+// dL/dSigma = T^T G T, upper triangle (backward.cuh:82-107)
+__device__ __forceinline__ Sym3 grad_cov3d(const M23& T, const Sym2& g) {
+    const float e0 = T.r0x * g.a + T.r1x * g.b, e1 = T.r0x * g.b + T.r1x * g.c;
+    const float e2 = T.r0y * g.a + T.r1y * g.b, e3 = T.r0y * g.b + T.r1y * g.c;
+    const float e4 = T.r0z * g.a + T.r1z * g.b, e5 = T.r0z * g.b + T.r1z * g.c;
+    Sym3 d;
+    d.xx = e0 * T.r0x + e1 * T.r1x;
+    d.xy = e0 * T.r0y + e1 * T.r1y;
+    d.xz = e0 * T.r0z + e1 * T.r1z;
+    d.yy = e2 * T.r0y + e3 * T.r1y;
+    d.yz = e2 * T.r0z + e3 * T.r1z;
+    d.zz = e4 * T.r0z + e5 * T.r1z;
+    return d;
+}
+
+// dL/dM = 2 G_full M (backward.cuh:123-153)
+__device__ __forceinline__ M3 grad_M(const Sym3& d, const M3& M) {
+    M3 o;
+    o.m00 = 2.0f * (d.xx * M.m00 + d.xy * M.m10 + d.xz * M.m20);
+    o.m01 = 2.0f * (d.xx * M.m01 + d.xy * M.m11 + d.xz * M.m21);
+    o.m02 = 2.0f * (d.xx * M.m02 + d.xy * M.m12 + d.xz * M.m22);
+    o.m10 = 2.0f * (d.xy * M.m00 + d.yy * M.m10 + d.yz * M.m20);
+    o.m11 = 2.0f * (d.xy * M.m01 + d.yy * M.m11 + d.yz * M.m21);
+    o.m12 = 2.0f * (d.xy * M.m02 + d.yy * M.m12 + d.yz * M.m22);
+    o.m20 = 2.0f * (d.xz * M.m00 + d.yz * M.m10 + d.zz * M.m20);
+    o.m21 = 2.0f * (d.xz * M.m01 + d.yz * M.m11 + d.zz * M.m21);
+    o.m22 = 2.0f * (d.xz * M.m02 + d.yz * M.m12 + d.zz * M.m22);
+    return o;
+}
+
+// dL/dq (raw, unnormalised) from dL/dR (backward.cuh:168-227)
+__device__ __forceinline__ float4 grad_quat(const QuatRot& q, const M3& g) {
+    const float w = q.w, x = q.x, y = q.y, z = q.z;
+    const float dw = 2.0f * (-z * g.m01 + y * g.m02 + z * g.m10 - x * g.m12 + -y * g.m20 + x * g.m21);
+    const float dx = 2.0f * (y * g.m01 + z * g.m02 + y * g.m10 - 2.0f * x * g.m11 - w * g.m12 +
+                             z * g.m20 + w * g.m21 - 2.0f * x * g.m22);
+    const float dy = 2.0f * (-2.0f * y * g.m00 + x * g.m01 + w * g.m02 + x * g.m10 + z * g.m12 +
+                             -w * g.m20 + z * g.m21 - 2.0f * y * g.m22);
+    const float dz = 2.0f * (-2.0f * z * g.m00 - w * g.m01 + x * g.m02 + w * g.m10 -
+                             2.0f * z * g.m11 + y * g.m12 + x * g.m20 + y * g.m21);
+    const float dot = dw * w + dx * x + dy * y + dz * z;
+    return make_float4(q.inv_norm * (dw - w * dot), q.inv_norm * (dx - x * dot),
+                       q.inv_norm * (dy - y * dot), q.inv_norm * (dz - z * dot));
+}
+
+// Contribution of Sigma' to dL/dt through J(t) (backward.cuh:248-346); adds into dt.
+__device__ __forceinline__ void add_grad_t_from_cov(const Sym2& g, const Sym3& S, const M3& W, V3 t,
+                                                    float fx, float fy, const Jac& J, const M23& T, V3& dt) {
+    const M23 TS = times_sym3(T, S);
+    const float k0 = 2.0f * (g.a * TS.r0x + g.b * TS.r1x), k1 = 2.0f * (g.a * TS.r0y + g.b * TS.r1y);
+    const float k2 = 2.0f * (g.a * TS.r0z + g.b * TS.r1z), k3 = 2.0f * (g.b * TS.r0x + g.c * TS.r1x);
+    const float k4 = 2.0f * (g.b * TS.r0y + g.c * TS.r1y), k5 = 2.0f * (g.b * TS.r0z + g.c * TS.r1z);
+    const float j0 = k0 * W.m00 + k1 * W.m01 + k2 * W.m02;     // dL/dJ[0][0]
+    const float j2 = k0 * W.m20 + k1 * W.m21 + k2 * W.m22;     // dL/dJ[0][2]
+    const float j4 = k3 * W.m10 + k4 * W.m11 + k5 * W.m12;     // dL/dJ[1][1]
+    const float j5 = k3 * W.m20 + k4 * W.m21 + k5 * W.m22;     // dL/dJ[1][2]
+    const float tz_inv3 = J.tz_inv2 * J.tz_inv;
+    dt.x += j2 * (-fx * J.tz_inv2);
+    dt.y += j5 * (-fy * J.tz_inv2);
+    dt.z += j0 * (-fx * J.tz_inv2) + j2 * (2.0f * fx * t.x * tz_inv3) + j4 * (-fy * J.tz_inv2) +
+            j5 * (2.0f * fy * t.y * tz_inv3);
+}
+
+struct PBPtrs {
+    const float* positions; const float* rotations; const float* scales; const float* opacities;
+    const float* sh; const int32_t* radii; const float* rgb_clamped;
+    const float* grad_accum;
+    const float* g_means; const float* g_cov; const float* g_rgb; const float* g_opa;
+    float* d_pos; float* d_rot; float* d_scl; float* d_opa; float* d_sh; float* d_means_out;
+};
+
+template <int C, bool ALIGNED>
+__global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int degree, CamArgs cam, PBPtrs p) {
+    constexpr int LROW = ShTile<C>::LROW;
+    __shared__ float s_sh[CUGS_BLOCK * LROW];
+    const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
+    const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
+    const int64_t idx = base + threadIdx.x;
+    const bool live = idx < n;
+    const int num_active = active_count(degree);
+
+    const bool gate_from_sh = (p.rgb_clamped == nullptr);      // kernel-uniform
+    if (gate_from_sh) {
+        load_sh_rows<C, ALIGNED>(p.sh, base, count, s_sh);
+        __syncthreads();
+    }
+
+    float Y[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float gated[3] = {0.0f, 0.0f, 0.0f};
+    V3 pos{0.0f, 0.0f, 0.0f};
+    float g_mx = 0.0f, g_my = 0.0f, g_opa = 0.0f;
+    Sym2 g_inv{0.0f, 0.0f, 0.0f};
+    if (live) {
+        pos = V3{p.positions[idx * 3 + 0], p.positions[idx * 3 + 1], p.positions[idx * 3 + 2]};
+        float g_rgb[3];
+        if (p.grad_accum) {
+            const float4* row = reinterpret_cast<const float4*>(p.grad_accum + idx * CUGS_GRAD_STRIDE);
+            const float4 r0 = row[0], r1 = row[1];
+            g_rgb[0] = r0.x; g_rgb[1] = r0.y; g_rgb[2] = r0.z; g_opa = r0.w;
+            g_mx = r1.x; g_my = r1.y; g_inv.a = r1.z; g_inv.b = r1.w;
+            g_inv.c = p.grad_accum[idx * CUGS_GRAD_STRIDE + 8];
+        } else {
+            g_rgb[0] = p.g_rgb[idx * 3 + 0]; g_rgb[1] = p.g_rgb[idx * 3 + 1]; g_rgb[2] = p.g_rgb[idx * 3 + 2];
+            g_opa = p.g_opa[idx];
+            g_mx = p.g_means[idx * 2 + 0]; g_my = p.g_means[idx * 2 + 1];
+            g_inv = Sym2{p.g_cov[idx * 3 + 0], p.g_cov[idx * 3 + 1], p.g_cov[idx * 3 + 2]};
+        }
+        sh_basis(degree, view_direction(pos, cam), Y);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            bool open;
+            if (gate_from_sh) open = raw_colour(s_sh + threadIdx.x * LROW + ch * C, Y, num_active) > 0.0f;
+            else open = p.rgb_clamped[idx * 3 + ch] > 0.0f;
+            gated[ch] = g_rgb[ch] * (open ? 1.0f : 0.0f);          // sh_backward.cu:99-100
+        }
+    }
+    if (gate_from_sh) __syncthreads();                         // coefficients consumed; reuse the tile
+
+    if (live) {
+        float* row = s_sh + threadIdx.x * LROW;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int k = 0; k < C; ++k) row[ch * C + k] = (k < num_active) ? gated[ch] * Y[k] : 0.0f;
+    }
+    __syncthreads();
+    store_sh_rows<C, ALIGNED>(p.d_sh, base, count, s_sh);
+    if (!live) return;
+
+    // ---- geometry ----
+    V3 d_pos{0.0f, 0.0f, 0.0f}, d_log{0.0f, 0.0f, 0.0f};
+    float4 d_q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float d_logit = 0.0f;
+    if (p.radii[idx] > 0) {                                    // projection_backward.cu:48
+        const M3 W = view_rotation(cam);
+        const V3 t = to_camera(cam, W, pos);
+        const V3 s{cugs_expf(p.scales[idx * 3 + 0] + cam.log_mod), cugs_expf(p.scales[idx * 3 + 1] + cam.log_mod),
+                   cugs_expf(p.scales[idx * 3 + 2] + cam.log_mod)};
+        const float4 q = ALIGNED ? reinterpret_cast<const float4*>(p.rotations)[idx]
+                                 : make_float4(p.rotations[idx * 4 + 0], p.rotations[idx * 4 + 1],
+                                               p.rotations[idx * 4 + 2], p.rotations[idx * 4 + 3]);
+        const QuatRot qr = rotation_of(q.x, q.y, q.z, q.w);
+        const M3 M = scale_columns(qr.R, s);
+        const Sym3 S = gram(M);
+        const Jac J = jacobian(t, cam.fx, cam.fy);
+        const Sym2 cov = screen_covariance(project_matrix_full(J, W), S);
+        Sym2 inv;
+        if (invert_sym2(cov, inv) > 0.0f) {                    // projection_backward.cu:91
+            const M23 T = project_matrix_sparse(J, W);
+            const Sym2 g_cov = grad_cov_from_inv(inv, g_inv);
+            const Sym3 g_S = grad_cov3d(T, g_cov);
+            const M3 g_M = grad_M(g_S, M);
+            // M = R diag(s): dL/dR_ij = dL/dM_ij s_j; dL/ds_j = sum_i dL/dM_ij R_ij; x s_j for log-space
+            const M3 g_R{g_M.m00 * s.x, g_M.m01 * s.y, g_M.m02 * s.z, g_M.m10 * s.x, g_M.m11 * s.y,
+                         g_M.m12 * s.z, g_M.m20 * s.x, g_M.m21 * s.y, g_M.m22 * s.z};
+            const M3& R = qr.R;
+            d_log.x = (g_M.m00 * R.m00 + g_M.m10 * R.m10 + g_M.m20 * R.m20) * s.x;
+            d_log.y = (g_M.m01 * R.m01 + g_M.m11 * R.m11 + g_M.m21 * R.m21) * s.y;
+            d_log.z = (g_M.m02 * R.m02 + g_M.m12 * R.m12 + g_M.m22 * R.m22) * s.z;
+            d_q = grad_quat(qr, g_R);
+
+            V3 dt{0.0f, 0.0f, 0.0f};                            // projection_backward.cu:194-199
+            dt.x += g_mx * cam.fx * J.tz_inv;
+            dt.y += g_my * cam.fy * J.tz_inv;
+            dt.z += g_mx * (-cam.fx * t.x * J.tz_inv2) + g_my * (-cam.fy * t.y * J.tz_inv2);
+            add_grad_t_from_cov(g_cov, S, W, t, cam.fx, cam.fy, J, T, dt);
+            d_pos.x = W.m00 * dt.x + W.m10 * dt.y + W.m20 * dt.z;
+            d_pos.y = W.m01 * dt.x + W.m11 * dt.y + W.m21 * dt.z;
+            d_pos.z = W.m02 * dt.x + W.m12 * dt.y + W.m22 * dt.z;
+
+            const float sig = cugs_sigmoidf(p.opacities[idx]);
+            d_logit = g_opa * sig * (1.0f - sig);
+        }
+    }
+    p.d_pos[idx * 3 + 0] = d_pos.x; p.d_pos[idx * 3 + 1] = d_pos.y; p.d_pos[idx * 3 + 2] = d_pos.z;
+    if (ALIGNED) reinterpret_cast<float4*>(p.d_rot)[idx] = d_q;
+    else { p.d_rot[idx * 4 + 0] = d_q.x; p.d_rot[idx * 4 + 1] = d_q.y; p.d_rot[idx * 4 + 2] = d_q.z; p.d_rot[idx * 4 + 3] = d_q.w; }
+    p.d_scl[idx * 3 + 0] = d_log.x; p.d_scl[idx * 3 + 1] = d_log.y; p.d_scl[idx * 3 + 2] = d_log.z;
+    p.d_opa[idx] = d_logit;
+    if (p.d_means_out) { p.d_means_out[idx * 2 + 0] = g_mx; p.d_means_out[idx * 2 + 1] = g_my; }
+}
+
+// ---- standalone SH backward (evaluate_sh_backward_cuda, core/sh_backward.cu:114-156) ----
+template <int C, bool ALIGNED>
+__global__ __launch_bounds__(CUGS_BLOCK) void k_sh_backward(int64_t n, int degree, const float* __restrict__ sh,
+                                                            const float* __restrict__ dirs,
+                                                            const float* __restrict__ dL_dcolor,
+                                                            float* __restrict__ dL_dsh) {
+    constexpr int LROW = ShTile<C>::LROW;
+    __shared__ float s_sh[CUGS_BLOCK * LROW];
+    const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
+    const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
+    const int64_t idx = base + threadIdx.x;
+    const bool live = idx < n;
+    const int num_active = active_count(degree);
+    load_sh_rows<C, ALIGNED>(sh, base, count, s_sh);
+    __syncthreads();
+    float Y[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float gated[3] = {0.0f, 0.0f, 0.0f};
+    if (live) {
+        sh_basis(degree, V3{dirs[idx * 3 + 0], dirs[idx * 3 + 1], dirs[idx * 3 + 2]}, Y);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const bool open = raw_colour(s_sh + threadIdx.x * LROW + ch * C, Y, num_active) > 0.0f;
+            gated[ch] = dL_dcolor[idx * 3 + ch] * (open ? 1.0f : 0.0f);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        float* row = s_sh + threadIdx.x * LROW;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int k = 0; k < C; ++k) row[ch * C + k] = (k < num_active) ? gated[ch] * Y[k] : 0.0f;
+    }
+    __syncthreads();
+    store_sh_rows<C, ALIGNED>(dL_dsh, base, count, s_sh);
+}
+
+// Any other coefficient count: straight from/to global.
+__global__ __launch_bounds__(CUGS_BLOCK) void k_sh_backward_generic(int64_t n, int degree, int C,
+                                                                    const float* __restrict__ sh,
+                                                                    const float* __restrict__ dirs,
+                                                                    const float* __restrict__ dL_dcolor,
+                                                                    float* __restrict__ dL_dsh) {
+    const int64_t idx = (int64_t)blockIdx.x * CUGS_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const int num_active = active_count(degree);
+    float Y[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    sh_basis(degree, V3{dirs[idx * 3 + 0], dirs[idx * 3 + 1], dirs[idx * 3 + 2]}, Y);
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* c = sh + idx * 3 * C + (int64_t)ch * C;
+        float* d = dL_dsh + idx * 3 * C + (int64_t)ch * C;
+        float raw = 0.0f;
+        for (int k = 0; k < 16; ++k)
+            if (k < num_active) raw += c[k] * Y[k];
+        raw += 0.5f;
+        const float g = dL_dcolor[idx * 3 + ch] * ((raw > 0.0f) ? 1.0f : 0.0f);
+        for (int k = 0; k < 16; ++k)
+            if (k < num_active) d[k] = g * Y[k];
+        for (int k = num_active; k < C; ++k) d[k] = 0.0f;
+    }
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + CUGS_BLOCK - 1) / CUGS_BLOCK); }
+
+template <int C>
+int launch_pb(int64_t n, int degree, const CamArgs& cam, const PBPtrs& p, bool aligned, hipStream_t st) {
+    if (aligned)
+        hipLaunchKernelGGL((k_project_backward<C, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p);
+    else
+        hipLaunchKernelGGL((k_project_backward<C, false>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C>
+int launch_shb(int64_t n, int degree, const float* sh, const float* dirs, const float* g, float* out,
+               bool aligned, hipStream_t st) {
+    if (aligned)
+        hipLaunchKernelGGL((k_sh_backward<C, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, sh, dirs, g, out);
+    else
+        hipLaunchKernelGGL((k_sh_backward<C, false>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, sh, dirs, g, out);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cugs_project_backward(int64_t n, int num_coeffs, int active_degree, const float* positions,
+                                     const float* rotations, const float* scales, const float* opacities,
+                                     const float* sh_coeffs, const int32_t* radii, const float* rgb_clamped,
+                                     const cugs_camera* camera_host, float scale_modifier,
+                                     const float* grad_accum, const float* dL_dmeans_2d,
+                                     const float* dL_dcov_2d_inv, const float* dL_drgb,
+                                     const float* dL_dopacity_act, float* dL_dpositions, float* dL_drotations,
+                                     float* dL_dscales, float* dL_dopacities, float* dL_dsh_coeffs,
+                                     float* dL_dmeans_2d_out, void* stream) {
+    if (n < 0 || !camera_host) return CUGS_EINVAL;
+    if (active_degree < 0 || active_degree > 3) return CUGS_EINVAL;
+    if ((active_degree + 1) * (active_degree + 1) > num_coeffs) return CUGS_EINVAL;
+    if (num_coeffs != 1 && num_coeffs != 4 && num_coeffs != 9 && num_coeffs != 16) return CUGS_EINVAL;
+    if (n == 0) return 0;
+    if (!positions || !rotations || !scales || !opacities || !radii || !dL_dpositions || !dL_drotations ||
+        !dL_dscales || !dL_dopacities || !dL_dsh_coeffs)
+        return CUGS_EINVAL;
+    if (!rgb_clamped && !sh_coeffs) return CUGS_EINVAL;
+    if (!grad_accum && (!dL_dmeans_2d || !dL_dcov_2d_inv || !dL_drgb || !dL_dopacity_act)) return CUGS_EINVAL;
+    if (grad_accum && !cugs_aligned16(grad_accum)) return CUGS_EALIGN;
+    const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
+    PBPtrs p{positions, rotations, scales, opacities, sh_coeffs, radii, rgb_clamped, grad_accum,
+             dL_dmeans_2d, dL_dcov_2d_inv, dL_drgb, dL_dopacity_act, dL_dpositions, dL_drotations,
+             dL_dscales, dL_dopacities, dL_dsh_coeffs, dL_dmeans_2d_out};
+    const bool aligned = cugs_aligned16(dL_dsh_coeffs) && cugs_aligned16(rotations) && cugs_aligned16(dL_drotations) &&
+                         (rgb_clamped || cugs_aligned16(sh_coeffs));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (num_coeffs) {
+        case 1: return launch_pb<1>(n, active_degree, cam, p, aligned, st);
+        case 4: return launch_pb<4>(n, active_degree, cam, p, aligned, st);
+        case 9: return launch_pb<9>(n, active_degree, cam, p, aligned, st);
+        default: return launch_pb<16>(n, active_degree, cam, p, aligned, st);
+    }
+}
+
+extern "C" int cugs_evaluate_sh_backward(int degree, int64_t n, int num_coeffs, const float* sh_coeffs,
+                                         const float* directions, const float* dL_dcolor, float* dL_dsh,
+                                         void* stream) {
+    if (degree < 0 || degree > 3 || n < 0) return CUGS_EINVAL;           // sh_backward.cu:120
+    if ((degree + 1) * (degree + 1) > num_coeffs) return CUGS_EINVAL;
+    if (n == 0) return 0;
+    if (!sh_coeffs || !directions || !dL_dcolor || !dL_dsh) return CUGS_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(dL_dsh);
+    switch (num_coeffs) {
+        case 1: return launch_shb<1>(n, degree, sh_coeffs, directions, dL_dcolor, dL_dsh, aligned, st);
+        case 4: return launch_shb<4>(n, degree, sh_coeffs, directions, dL_dcolor, dL_dsh, aligned, st);
+        case 9: return launch_shb<9>(n, degree, sh_coeffs, directions, dL_dcolor, dL_dsh, aligned, st);
+        case 16: return launch_shb<16>(n, degree, sh_coeffs, directions, dL_dcolor, dL_dsh, aligned, st);
+        default:
+            hipLaunchKernelGGL(k_sh_backward_generic, dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree,
+                               num_coeffs, sh_coeffs, directions, dL_dcolor, dL_dsh);
+            CUGS_LAUNCH_CHECK();
+            return 0;
+    }
+}

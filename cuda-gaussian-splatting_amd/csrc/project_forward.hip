@@ -1,0 +1,283 @@
+// project_forward.hip — per-Gaussian 3D->2D projection fused with SH colour (SURVEY §8 a3+a4).
+//
+// Replaces, in ONE launch: k_project_gaussians (rasterizer/projection.cu:55-189), the four libtorch
+// passes that build view directions (projection.cu:278-280), k_evaluate_sh (core/sh.cu:19-79),
+// clamp_min(0) (projection.cu:284) and the six zero-fills (projection.cu:214-219).
+//
+// gfx950 mapping: one thread per Gaussian, 256-thread workgroups.  The [n,3,C] SH rows (192 of
+// the 236 B/Gaussian at degree 3) would be a 192-byte-strided, fully uncoalesced per-thread read;
+// instead the workgroup's contiguous 256*3C-float chunk is streamed with 16-byte coalesced loads
+// into LDS (row stride padded to an odd number of dwords: conflict-free ds_read_b32 across the 32
+// banks) and each thread then reads its own row from LDS.  Bound: HBM, algorithmic bytes
+// 44 + 12C read + 48 (+48 packed) written per Gaussian.
+#include "cugs_gaussian_math.h"
+
+namespace {
+
+template <int C>
+struct ShTile {
+    static constexpr int ROW = 3 * C;
+    static constexpr int LROW = (ROW % 2 == 0) ? ROW + 1 : ROW;   // odd dword stride
+};
+
+// Stream the workgroup's SH chunk (count rows of ROW floats starting at row `base`) into LDS.
+template <int C, bool ALIGNED>
+__device__ __forceinline__ void stage_sh_rows(const float* __restrict__ sh, int64_t base, int count,
+                                              float* s_sh) {
+    constexpr int ROW = ShTile<C>::ROW, LROW = ShTile<C>::LROW;
+    const float* src = sh + base * ROW;
+    const int total = count * ROW;
+    const int tid = threadIdx.x;
+    if (ALIGNED) {
+        const int total4 = total >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        for (int e4 = tid; e4 < total4; e4 += CUGS_BLOCK) {
+            float4 v = src4[e4];
+            int e = e4 * 4;
+            int row = e / ROW, col = e - row * ROW;
+            float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_sh[row * LROW + col] = vals[k];
+                if (++col == ROW) { col = 0; ++row; }
+            }
+        }
+        for (int e = (total4 << 2) + tid; e < total; e += CUGS_BLOCK) {
+            int row = e / ROW, col = e - row * ROW;
+            s_sh[row * LROW + col] = src[e];
+        }
+    } else {
+        for (int e = tid; e < total; e += CUGS_BLOCK) {
+            int row = e / ROW, col = e - row * ROW;
+            s_sh[row * LROW + col] = src[e];
+        }
+    }
+}
+
+struct ProjPtrs {
+    const float* positions; const float* rotations; const float* scales; const float* opacities;
+    const float* sh;
+    float* means_2d; float* depths; float* cov_2d_inv; int32_t* radii; int32_t* tiles_touched;
+    float* opacities_act; float* rgb; float* packed;
+};
+
+template <int C, bool ALIGNED>
+__global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int degree, CamArgs cam,
+                                                                ProjPtrs p) {
+    constexpr int LROW = ShTile<C>::LROW;
+    __shared__ float s_sh[CUGS_BLOCK * LROW];
+
+    const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
+    const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
+    stage_sh_rows<C, ALIGNED>(p.sh, base, count, s_sh);
+    __syncthreads();
+
+    const int64_t idx = base + threadIdx.x;
+    if (idx >= n) return;
+
+    const V3 pos{p.positions[idx * 3 + 0], p.positions[idx * 3 + 1], p.positions[idx * 3 + 2]};
+
+    // --- colour: evaluated for every Gaussian, culled ones included ---
+    const V3 dir = view_direction(pos, cam);
+    const float* row = s_sh + threadIdx.x * LROW;
+    float col[3];
+    // (raw < 0 ? 0 : raw) rather than fmaxf: clamp_min keeps a NaN, fmaxf would drop it.
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float raw = sh_colour(degree, row + ch * C, 1, dir);
+        col[ch] = (raw < 0.0f) ? 0.0f : raw;
+        p.rgb[idx * 3 + ch] = col[ch];
+    }
+
+    // --- geometry ---
+    float mx = 0.0f, my = 0.0f, depth = 0.0f, opa = 0.0f;
+    Sym2 inv{0.0f, 0.0f, 0.0f};
+    int radius = 0, tiles = 0;
+
+    const M3 W = view_rotation(cam);
+    const V3 t = to_camera(cam, W, pos);
+    if (t.z > 0.2f) {                                       // near-plane cull, projection.cu:104
+        mx = cam.fx * t.x / t.z + cam.cx;
+        my = cam.fy * t.y / t.z + cam.cy;
+        depth = t.z;
+        opa = cugs_sigmoidf(p.opacities[idx]);
+
+        const V3 s{cugs_expf(p.scales[idx * 3 + 0] + cam.log_mod),
+                   cugs_expf(p.scales[idx * 3 + 1] + cam.log_mod),
+                   cugs_expf(p.scales[idx * 3 + 2] + cam.log_mod)};
+        const float4 q = ALIGNED ? reinterpret_cast<const float4*>(p.rotations)[idx]
+                                 : make_float4(p.rotations[idx * 4 + 0], p.rotations[idx * 4 + 1],
+                                               p.rotations[idx * 4 + 2], p.rotations[idx * 4 + 3]);
+        const QuatRot qr = rotation_of(q.x, q.y, q.z, q.w);
+        const Sym3 S = gram(scale_columns(qr.R, s));
+        const Jac J = jacobian(t, cam.fx, cam.fy);
+        const Sym2 cov = screen_covariance(project_matrix_full(J, W), S);
+        Sym2 inv_c;
+        const float det = invert_sym2(cov, inv_c);
+        if (det > 0.0f) {                                   // projection.cu:152
+            inv = inv_c;
+            int r = splat_radius(cov);
+            if (r > 0) {                                    // projection.cu:162
+                r = min(r, max(cam.width, cam.height));
+                radius = r;
+                const int ntx = (cam.width + CUGS_TILE - 1) / CUGS_TILE;
+                const int nty = (cam.height + CUGS_TILE - 1) / CUGS_TILE;
+                const TileRect tr = tile_rect_of(mx, my, r, cam.width, cam.height, ntx, nty);
+                tiles = max((tr.x1 - tr.x0) * (tr.y1 - tr.y0), 0);
+            }
+        }
+    }
+
+    p.means_2d[idx * 2 + 0] = mx;
+    p.means_2d[idx * 2 + 1] = my;
+    p.depths[idx] = depth;
+    p.cov_2d_inv[idx * 3 + 0] = inv.a;
+    p.cov_2d_inv[idx * 3 + 1] = inv.b;
+    p.cov_2d_inv[idx * 3 + 2] = inv.c;
+    p.radii[idx] = radius;
+    p.tiles_touched[idx] = tiles;
+    p.opacities_act[idx] = opa;
+    if (p.packed) write_packed(p.packed, idx, mx, my, inv, col[0], col[1], col[2], opa);
+}
+
+// ---- standalone SH forward (evaluate_sh_cuda, core/sh.cu:81-123): unclamped ----
+template <int C, bool ALIGNED>
+__global__ __launch_bounds__(CUGS_BLOCK) void k_sh_forward(int64_t n, int degree,
+                                                           const float* __restrict__ sh,
+                                                           const float* __restrict__ dirs,
+                                                           float* __restrict__ out) {
+    constexpr int LROW = ShTile<C>::LROW;
+    __shared__ float s_sh[CUGS_BLOCK * LROW];
+    const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
+    const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
+    stage_sh_rows<C, ALIGNED>(sh, base, count, s_sh);
+    __syncthreads();
+    const int64_t idx = base + threadIdx.x;
+    if (idx >= n) return;
+    const V3 d{dirs[idx * 3 + 0], dirs[idx * 3 + 1], dirs[idx * 3 + 2]};
+    const float* row = s_sh + threadIdx.x * LROW;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) out[idx * 3 + ch] = sh_colour(degree, row + ch * C, 1, d);
+}
+
+// Generic-C fallbacks (C not in {1,4,9,16}): one thread per Gaussian straight from global.
+__global__ __launch_bounds__(CUGS_BLOCK) void k_sh_forward_generic(int64_t n, int degree, int C,
+                                                                   const float* __restrict__ sh,
+                                                                   const float* __restrict__ dirs,
+                                                                   float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * CUGS_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const V3 d{dirs[idx * 3 + 0], dirs[idx * 3 + 1], dirs[idx * 3 + 2]};
+    for (int ch = 0; ch < 3; ++ch)
+        out[idx * 3 + ch] = sh_colour(degree, sh + idx * 3 * C + (int64_t)ch * C, 1, d);
+}
+
+__global__ __launch_bounds__(CUGS_BLOCK) void k_pack_projected(int64_t n,
+                                                               const float* __restrict__ means_2d,
+                                                               const float* __restrict__ cov_2d_inv,
+                                                               const float* __restrict__ rgb,
+                                                               const float* __restrict__ opa,
+                                                               float* __restrict__ packed) {
+    const int64_t idx = (int64_t)blockIdx.x * CUGS_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    Sym2 inv{cov_2d_inv[idx * 3 + 0], cov_2d_inv[idx * 3 + 1], cov_2d_inv[idx * 3 + 2]};
+    write_packed(packed, idx, means_2d[idx * 2 + 0], means_2d[idx * 2 + 1], inv, rgb[idx * 3 + 0],
+                 rgb[idx * 3 + 1], rgb[idx * 3 + 2], opa[idx]);
+}
+
+inline int grid_for(int64_t n) { return (int)((n + CUGS_BLOCK - 1) / CUGS_BLOCK); }
+
+template <int C>
+int launch_project(int64_t n, int degree, const CamArgs& cam, const ProjPtrs& p, bool aligned,
+                   hipStream_t st) {
+    if (aligned)
+        hipLaunchKernelGGL((k_project_forward<C, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n,
+                           degree, cam, p);
+    else
+        hipLaunchKernelGGL((k_project_forward<C, false>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n,
+                           degree, cam, p);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C>
+int launch_sh_forward(int64_t n, int degree, const float* sh, const float* dirs, float* out,
+                      bool aligned, hipStream_t st) {
+    if (aligned)
+        hipLaunchKernelGGL((k_sh_forward<C, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n,
+                           degree, sh, dirs, out);
+    else
+        hipLaunchKernelGGL((k_sh_forward<C, false>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n,
+                           degree, sh, dirs, out);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cugs_project_forward(int64_t n, int num_coeffs, int active_degree,
+                                    const float* positions, const float* rotations,
+                                    const float* scales, const float* opacities,
+                                    const float* sh_coeffs, const cugs_camera* camera_host,
+                                    float scale_modifier, float* means_2d, float* depths,
+                                    float* cov_2d_inv, int32_t* radii, int32_t* tiles_touched,
+                                    float* opacities_act, float* rgb, float* packed, void* stream) {
+    if (n < 0 || !camera_host) return CUGS_EINVAL;
+    if (active_degree < 0 || active_degree > 3) return CUGS_EINVAL;
+    if ((active_degree + 1) * (active_degree + 1) > num_coeffs) return CUGS_EINVAL;
+    if (num_coeffs != 1 && num_coeffs != 4 && num_coeffs != 9 && num_coeffs != 16) return CUGS_EINVAL;
+    if (n == 0) return 0;
+    if (!positions || !rotations || !scales || !opacities || !sh_coeffs || !means_2d || !depths ||
+        !cov_2d_inv || !radii || !tiles_touched || !opacities_act || !rgb)
+        return CUGS_EINVAL;
+    if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
+    if (n > (int64_t)2147483647) return CUGS_EOVERFLOW;
+
+    const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
+    ProjPtrs p{positions, rotations, scales, opacities, sh_coeffs, means_2d, depths, cov_2d_inv,
+               radii, tiles_touched, opacities_act, rgb, packed};
+    const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rotations);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (num_coeffs) {
+        case 1: return launch_project<1>(n, active_degree, cam, p, aligned, st);
+        case 4: return launch_project<4>(n, active_degree, cam, p, aligned, st);
+        case 9: return launch_project<9>(n, active_degree, cam, p, aligned, st);
+        default: return launch_project<16>(n, active_degree, cam, p, aligned, st);
+    }
+}
+
+extern "C" int cugs_evaluate_sh(int degree, int64_t n, int num_coeffs, const float* sh_coeffs,
+                                const float* directions, float* out_rgb, void* stream) {
+    // Input validation of evaluate_sh_cuda (core/sh.cu:84-97)
+    if (degree < 0 || degree > 3 || n < 0) return CUGS_EINVAL;
+    if ((degree + 1) * (degree + 1) > num_coeffs) return CUGS_EINVAL;
+    if (n == 0) return 0;
+    if (!sh_coeffs || !directions || !out_rgb) return CUGS_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool aligned = cugs_aligned16(sh_coeffs);
+    switch (num_coeffs) {
+        case 1: return launch_sh_forward<1>(n, degree, sh_coeffs, directions, out_rgb, aligned, st);
+        case 4: return launch_sh_forward<4>(n, degree, sh_coeffs, directions, out_rgb, aligned, st);
+        case 9: return launch_sh_forward<9>(n, degree, sh_coeffs, directions, out_rgb, aligned, st);
+        case 16: return launch_sh_forward<16>(n, degree, sh_coeffs, directions, out_rgb, aligned, st);
+        default:
+            hipLaunchKernelGGL(k_sh_forward_generic, dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n,
+                               degree, num_coeffs, sh_coeffs, directions, out_rgb);
+            CUGS_LAUNCH_CHECK();
+            return 0;
+    }
+}
+
+extern "C" int cugs_pack_projected(int64_t n, const float* means_2d, const float* cov_2d_inv,
+                                   const float* rgb, const float* opacities_act, float* packed,
+                                   void* stream) {
+    if (n < 0) return CUGS_EINVAL;
+    if (n == 0) return 0;
+    if (!means_2d || !cov_2d_inv || !rgb || !opacities_act || !packed) return CUGS_EINVAL;
+    if (!cugs_aligned16(packed)) return CUGS_EALIGN;
+    hipLaunchKernelGGL(k_pack_projected, dim3(grid_for(n)), dim3(CUGS_BLOCK), 0,
+                       static_cast<hipStream_t>(stream), n, means_2d, cov_2d_inv, rgb, opacities_act,
+                       packed);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,125 @@
+// raster_forward.hip — per-16x16-tile front-to-back alpha blend.
+//
+// Replaces rasterize_forward / k_rasterize_forward (rasterizer/forward.cu:180-240, :48-174) and its
+// three output fills (forward.cu:197-199).  Semantics kept exactly (they decide n_contrib and the
+// image): pixel centre px+0.5 (:72-73); skip if power > 0 (:135); alpha = min(0.99, o e^power)
+// (:137-140); skip if alpha < 1/255 (:141); C += alpha T rgb, T *= 1-alpha, count++ and THEN stop
+// when T < 1/255 (:143-156); out = C + T bg (:165-167).
+//
+// gfx950 design: see cugs_raster_common.h (4 waves x 8x8 quads, LDS-staged 256-record batches,
+// wave64 ballot compaction of the records each quad can see).  The inner loop is VALU-bound
+// (~35 instructions per surviving (pixel, Gaussian) evaluation); HBM traffic is the 4 B index +
+// 48 B record per (tile, Gaussian) pair plus 20 B per pixel written.
+#include "cugs_raster_common.h"
+
+namespace {
+
+template <bool PACKED>
+__global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, RasterSrc src,
+                                                               float* __restrict__ out_color,
+                                                               float* __restrict__ out_final_T,
+                                                               int32_t* __restrict__ out_n_contrib) {
+    __shared__ float4 s_rec[CUGS_BLOCK * CUGS_REC_F4];
+    __shared__ int s_wave_done[4];
+
+    const unsigned tile = cugs_xcd_remap(blockIdx.x, (unsigned)geo.ntiles);
+    const int tile_x = (int)(tile % (unsigned)geo.ntx), tile_y = (int)(tile / (unsigned)geo.ntx);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int quad_x = tile_x * CUGS_TILE + (wave & 1) * 8, quad_y = tile_y * CUGS_TILE + (wave >> 1) * 8;
+    const int px = quad_x + (lane & 7), py = quad_y + (lane >> 3);
+    const bool inside = (px < geo.width) && (py < geo.height);
+    const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+    const float qx0 = (float)quad_x + 0.5f, qy0 = (float)quad_y + 0.5f;
+
+    const int range_start = src.tile_ranges[tile * 2 + 0];
+    const int range_end = src.tile_ranges[tile * 2 + 1];
+    const int num_in_range = range_end - range_start;
+    const int num_batches = (num_in_range + CUGS_BLOCK - 1) / CUGS_BLOCK;
+
+    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    int count = 0;
+    bool done = !inside;
+    bool wave_done = (__ballot(!done) == 0ull);
+
+    for (int batch = 0; batch < num_batches; ++batch) {
+        // whole-tile early exit (forward.cu:97-101), one flag per wave instead of an atomicMin
+        if (lane == 0) s_wave_done[wave] = wave_done ? 1 : 0;
+        __syncthreads();
+        if (s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) break;
+
+        stage_record<PACKED>(src, range_start + batch * CUGS_BLOCK + tid, range_end, s_rec);
+        __syncthreads();
+
+        if (!wave_done) {
+            const int batch_count = min(CUGS_BLOCK, num_in_range - batch * CUGS_BLOCK);
+            for (int sub = 0; sub * CUGS_WAVE < batch_count && !wave_done; ++sub) {
+                const int j = sub * CUGS_WAVE + lane;
+                bool hit = false;
+                if (j < batch_count)
+                    hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1],
+                                         s_rec[j * CUGS_REC_F4 + 2], qx0, qy0);
+                unsigned long long mask = __ballot(hit);
+                while (mask) {
+                    const int jj = sub * CUGS_WAVE + __builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    const float4 g0 = s_rec[jj * CUGS_REC_F4 + 0];     // wave-uniform address: broadcast
+                    const float4 g1 = s_rec[jj * CUGS_REC_F4 + 1];
+                    const float o = s_rec[jj * CUGS_REC_F4 + 2].x;
+                    if (!done) {
+                        PixelEval e;
+                        if (pixel_alpha(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, o, e)) {
+                            const float weight = e.alpha * T;
+                            C0 = fmaf(weight, g1.y, C0);
+                            C1 = fmaf(weight, g1.z, C1);
+                            C2 = fmaf(weight, g1.w, C2);
+                            T *= (1.0f - e.alpha);
+                            ++count;
+                            if (T < (1.0f / 255.0f)) done = true;
+                        }
+                    }
+                    if (__ballot(!done) == 0ull) { wave_done = true; break; }
+                }
+            }
+        }
+    }
+
+    if (inside) {
+        const int pix = py * geo.width + px;
+        out_color[pix * 3 + 0] = fmaf(T, geo.bg0, C0);
+        out_color[pix * 3 + 1] = fmaf(T, geo.bg1, C1);
+        out_color[pix * 3 + 2] = fmaf(T, geo.bg2, C2);
+        out_final_T[pix] = T;
+        out_n_contrib[pix] = count;
+    }
+}
+
+}  // namespace
+
+extern "C" int cugs_rasterize_forward(int width, int height, const float background_host[3],
+                                      const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                                      const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                      const float* opacities_act, const float* packed, float* out_color,
+                                      float* out_final_T, int32_t* out_n_contrib, void* stream) {
+    if (width < 0 || height < 0 || !background_host) return CUGS_EINVAL;
+    const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
+    if (ntx == 0 || nty == 0) return 0;                       // forward.cu:204-210: nothing to draw
+    if (!tile_ranges || !out_color || !out_final_T || !out_n_contrib) return CUGS_EINVAL;
+    if (!packed && (!means_2d || !cov_2d_inv || !rgb || !opacities_act)) {
+        // An empty scene has empty per-Gaussian arrays; the tile ranges are then all {0,0} and no
+        // record is ever read, so NULL sources are acceptable only together with NULL indices.
+        if (gaussian_indices) return CUGS_EINVAL;
+    }
+    if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
+    if ((int64_t)width * height > 2147483647ll / 3) return CUGS_EOVERFLOW;
+    RasterGeom geo{width, height, ntx, ntx * nty, background_host[0], background_host[1], background_host[2]};
+    RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (packed)
+        hipLaunchKernelGGL((k_raster_forward<true>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src,
+                           out_color, out_final_T, out_n_contrib);
+    else
+        hipLaunchKernelGGL((k_raster_forward<false>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src,
+                           out_color, out_final_T, out_n_contrib);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}

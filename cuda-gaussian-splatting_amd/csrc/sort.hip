@@ -1,0 +1,430 @@
+// sort.hip — (tile | depth) ordering of (tile, Gaussian) pairs.
+//
+// Replaces sort_gaussians (rasterizer/sorting.cu:115-227): the int32 cumsum + blocking .item()
+// (:145-146), k_fill_sort_pairs (:30-72), cub::DeviceRadixSort::SortPairs over all 64 key bits
+// (:191-210) and k_compute_tile_ranges (:82-109).
+//
+// Required result (bit-exact): pairs ordered by the 64-bit key (tile_id << 32 | float_bits(depth)),
+// ties in ascending Gaussian index (CUB's sort is stable and the reference fills in index order).
+//
+// How it is produced here (not the reference's schedule): a stable LSD sort by the full key is the
+// same permutation as (1) a stable sort of the N Gaussians by depth bits, (2) emitting each
+// Gaussian's pairs in that order, (3) a stable sort of the P pairs by tile id alone.  (1) moves
+// 8 B x N x 4 passes, (3) moves 8 B x P x ceil(log2(tiles)/8) passes (2 at 1080p) instead of
+// 12 B x P x 8 passes.  Every pass is the same three kernels: per-workgroup digit histogram,
+// per-digit row scan, stable scatter with wave64 ballot ranking.  All HBM-bound integer work.
+#include "cugs_gaussian_math.h"
+
+namespace {
+
+constexpr int RADIX = 256;
+constexpr int IPT = 16;                           // items per thread
+constexpr int CHUNK = CUGS_BLOCK * IPT;           // 4096 items per workgroup
+constexpr int WAVE_ITEMS = CUGS_WAVE * IPT;       // 1024 contiguous items per wave
+constexpr int FILL_IPT = 4;
+constexpr int FILL_CHUNK = CUGS_BLOCK * FILL_IPT; // Gaussians per workgroup in scan/fill
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline uint32_t nblocks_for(int64_t count, int chunk) { return (uint32_t)((count + chunk - 1) / chunk); }
+
+struct SortWs {
+    unsigned long long* total;   // pair-count accumulator
+    uint32_t* dkey[2];           // depth bits, ping-pong              [n]
+    uint32_t* dval[2];           // Gaussian index, ping-pong          [n]
+    uint32_t* hist;              // [RADIX][nblk] digit-major
+    uint32_t* tot;               // [RADIX]
+    uint32_t* blocksum;          // per FILL_CHUNK block pair counts   [nfill + 1]
+    uint32_t* ptile[2];          // tile id per pair, ping-pong        [P]
+    uint32_t* pidx[2];           // Gaussian index per pair            [P] (second one only if needed)
+    size_t bytes;
+};
+
+SortWs carve(void* base, int64_t n, int64_t max_pairs) {
+    SortWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    char* b = static_cast<char*>(base);
+    const uint32_t nblk_n = nblocks_for(n, CHUNK), nblk_p = nblocks_for(max_pairs, CHUNK);
+    const uint32_t nblk = nblk_n > nblk_p ? nblk_n : nblk_p;
+    size_t o_total = take(256);
+    size_t o_dk0 = take(sizeof(uint32_t) * (size_t)n), o_dk1 = take(sizeof(uint32_t) * (size_t)n);
+    size_t o_dv0 = take(sizeof(uint32_t) * (size_t)n), o_dv1 = take(sizeof(uint32_t) * (size_t)n);
+    size_t o_hist = take(sizeof(uint32_t) * (size_t)RADIX * (nblk + 1));
+    size_t o_tot = take(sizeof(uint32_t) * RADIX);
+    size_t o_bs = take(sizeof(uint32_t) * ((size_t)nblocks_for(n, FILL_CHUNK) + 2));
+    size_t o_pt0 = take(sizeof(uint32_t) * (size_t)max_pairs), o_pt1 = take(sizeof(uint32_t) * (size_t)max_pairs);
+    size_t o_pi0 = take(sizeof(uint32_t) * (size_t)max_pairs), o_pi1 = take(sizeof(uint32_t) * (size_t)max_pairs);
+    w.bytes = off;
+    w.total = reinterpret_cast<unsigned long long*>(b + o_total);
+    w.dkey[0] = reinterpret_cast<uint32_t*>(b + o_dk0); w.dkey[1] = reinterpret_cast<uint32_t*>(b + o_dk1);
+    w.dval[0] = reinterpret_cast<uint32_t*>(b + o_dv0); w.dval[1] = reinterpret_cast<uint32_t*>(b + o_dv1);
+    w.hist = reinterpret_cast<uint32_t*>(b + o_hist);
+    w.tot = reinterpret_cast<uint32_t*>(b + o_tot);
+    w.blocksum = reinterpret_cast<uint32_t*>(b + o_bs);
+    w.ptile[0] = reinterpret_cast<uint32_t*>(b + o_pt0); w.ptile[1] = reinterpret_cast<uint32_t*>(b + o_pt1);
+    w.pidx[0] = reinterpret_cast<uint32_t*>(b + o_pi0); w.pidx[1] = reinterpret_cast<uint32_t*>(b + o_pi1);
+    return w;
+}
+
+// ------------------------------------------------------------------------------------
+// wave / workgroup scan helpers (low-frequency paths; plain shuffles)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread over a 256-thread workgroup; *total = workgroup sum.
+// s_tmp: 4 dwords of LDS.  Contains two barriers.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    uint32_t w0 = s_tmp[0], w1 = s_tmp[1], w2 = s_tmp[2], w3 = s_tmp[3];
+    uint32_t base = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+    if (total) *total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------
+// sum(tiles_touched): the reference's cumsum[-1].item() (sorting.cu:145-146)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CUGS_BLOCK) void k_sum_tiles(int64_t n, const int32_t* __restrict__ tiles,
+                                                          unsigned long long* total) {
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * CUGS_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * CUGS_BLOCK)
+        acc += (unsigned long long)(uint32_t)tiles[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    __shared__ unsigned long long s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(total, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
+// ------------------------------------------------------------------------------------
+// One radix pass = hist + row scan + scatter.  SRC_DEPTH: first pass of the depth sort reads
+// the float depths directly and generates the index on the fly (no init kernel).
+// ------------------------------------------------------------------------------------
+template <bool SRC_DEPTH>
+__device__ __forceinline__ uint32_t load_key(const uint32_t* __restrict__ keys, uint32_t i) {
+    return keys[i];   // float bits reinterpreted by the caller's pointer cast when SRC_DEPTH
+}
+
+template <bool SRC_DEPTH>
+__global__ __launch_bounds__(CUGS_BLOCK) void k_radix_hist(const uint32_t* __restrict__ keys,
+                                                           uint32_t count, int shift, uint32_t mask,
+                                                           uint32_t* __restrict__ hist, uint32_t nblk) {
+    __shared__ uint32_t s_cnt[RADIX];
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t wbase = blockIdx.x * CHUNK + wave * WAVE_ITEMS;
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        uint32_t i = wbase + r * CUGS_WAVE + lane;
+        if (i < count) atomicAdd(&s_cnt[(load_key<SRC_DEPTH>(keys, i) >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+// Block d: exclusive scan of row d of hist (in place); tot[d] = row sum.
+__global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(uint32_t* __restrict__ hist,
+                                                                uint32_t nblk, uint32_t* __restrict__ tot) {
+    __shared__ uint32_t s_tmp[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblk; base += CUGS_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < nblk ? row[i] : 0u;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(v, s_tmp, &total);
+        if (i < nblk) row[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) tot[blockIdx.x] = carry;
+}
+
+template <bool SRC_DEPTH>
+__global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scatter(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count,
+    int shift, uint32_t mask, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ tot,
+    uint32_t nblk, uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t s_wave_base[4][RADIX];
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t wbase = blockIdx.x * CHUNK + wave * WAVE_ITEMS;
+
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_wave_base[w][tid] = 0;
+    __syncthreads();
+
+    uint32_t k[IPT], v[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        uint32_t i = wbase + r * CUGS_WAVE + lane;
+        bool ok = i < count;
+        k[r] = ok ? load_key<SRC_DEPTH>(keys_in, i) : 0xFFFFFFFFu;
+        v[r] = ok ? (SRC_DEPTH ? i : vals_in[i]) : 0u;
+        if (ok) atomicAdd(&s_wave_base[wave][(k[r] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+
+    // digit d (= tid): global base + this workgroup's offset, then split across the 4 waves
+    {
+        uint32_t dig_total = tot[tid];
+        uint32_t dig_base = block_exclusive_scan(dig_total, s_tmp, nullptr);
+        uint32_t b = dig_base + hist[tid * nblk + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t c = s_wave_base[w][tid];
+            s_wave_base[w][tid] = b;
+            b += c;
+        }
+    }
+    __syncthreads();
+
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const uint32_t i = wbase + r * CUGS_WAVE + lane;
+        const bool ok = i < count;
+        const uint32_t d = (k[r] >> shift) & mask;
+        // lanes of this wave holding the same digit (wave64 match-any via 8 ballots)
+        unsigned long long peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        if (ok) {
+            const uint32_t rank = __popcll(peers & lt_mask);
+            const uint32_t base = s_wave_base[wave][d];
+            const uint32_t dst = base + rank;
+            keys_out[dst] = k[r];
+            vals_out[dst] = v[r];
+            if ((peers >> lane) == 1ull)           // highest lane of the group advances the base
+                s_wave_base[wave][d] = base + __popcll(peers);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Pair emission in depth order
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CUGS_BLOCK) void k_fill_blocksums(uint32_t n,
+                                                               const uint32_t* __restrict__ order,
+                                                               const int32_t* __restrict__ tiles,
+                                                               uint32_t* __restrict__ blocksum) {
+    __shared__ uint32_t s_tmp[4];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < FILL_IPT; ++j) {
+        uint32_t i = blockIdx.x * FILL_CHUNK + threadIdx.x * FILL_IPT + j;
+        if (i < n) acc += (uint32_t)tiles[order[i]];
+    }
+    uint32_t total;
+    block_exclusive_scan(acc, s_tmp, &total);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+}
+
+// Single workgroup: exclusive scan of blocksum[0..nb) in place; blocksum[nb] = grand total.
+__global__ __launch_bounds__(CUGS_BLOCK) void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb) {
+    __shared__ uint32_t s_tmp[4];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += CUGS_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < nb ? blocksum[i] : 0u;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(v, s_tmp, &total);
+        if (i < nb) blocksum[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) blocksum[nb] = carry;
+}
+
+// k_fill_sort_pairs (sorting.cu:30-72), walked in depth order; only the tile id and the index are
+// stored (the depth half of the key is implied by the order).
+__global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
+    uint32_t n, uint32_t total_pairs, const uint32_t* __restrict__ order,
+    const int32_t* __restrict__ tiles, const float* __restrict__ means_2d,
+    const int32_t* __restrict__ radii, int img_w, int img_h, int ntx, int nty,
+    const uint32_t* __restrict__ blocksum, uint32_t* __restrict__ ptile, uint32_t* __restrict__ pidx) {
+    __shared__ uint32_t s_tmp[4];
+    uint32_t g[FILL_IPT], t[FILL_IPT], acc = 0;
+#pragma unroll
+    for (int j = 0; j < FILL_IPT; ++j) {
+        uint32_t i = blockIdx.x * FILL_CHUNK + threadIdx.x * FILL_IPT + j;
+        g[j] = i < n ? order[i] : 0u;
+        t[j] = i < n ? (uint32_t)tiles[g[j]] : 0u;
+        acc += t[j];
+    }
+    uint32_t pos = blocksum[blockIdx.x] + block_exclusive_scan(acc, s_tmp, nullptr);
+#pragma unroll
+    for (int j = 0; j < FILL_IPT; ++j) {
+        if (t[j] == 0) continue;
+        const uint32_t idx = g[j];
+        const int radius = radii[idx];
+        if (radius <= 0) continue;                                  // sorting.cu:44-45
+        const TileRect tr = tile_rect_of(means_2d[idx * 2 + 0], means_2d[idx * 2 + 1], radius, img_w,
+                                         img_h, ntx, nty);
+        uint32_t w = pos;
+        const uint32_t end = min(pos + t[j], total_pairs);         // never write past the buffers
+        for (int ty = tr.y0; ty < tr.y1; ++ty)
+            for (int tx = tr.x0; tx < tr.x1; ++tx) {
+                if (w < end) {
+                    ptile[w] = (uint32_t)(ty * ntx + tx);
+                    pidx[w] = idx;
+                }
+                ++w;
+            }
+        pos += t[j];
+    }
+}
+
+// k_compute_tile_ranges (sorting.cu:82-109) on the sorted tile ids; optionally rebuilds the
+// reference's sorted 64-bit keys (SortingOutput::gaussian_keys_sorted, sorting.hpp:20).
+__global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t total_pairs,
+                                                            const uint32_t* __restrict__ ptile,
+                                                            const int32_t* __restrict__ pidx,
+                                                            const float* __restrict__ depths,
+                                                            int32_t* __restrict__ tile_ranges,
+                                                            uint64_t* __restrict__ keys_sorted) {
+    const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
+    if (i >= total_pairs) return;
+    const uint32_t cur = ptile[i];
+    if (i == 0) {
+        tile_ranges[cur * 2 + 0] = 0;
+    } else {
+        const uint32_t prev = ptile[i - 1];
+        if (cur != prev) {
+            tile_ranges[prev * 2 + 1] = (int32_t)i;
+            tile_ranges[cur * 2 + 0] = (int32_t)i;
+        }
+    }
+    if (i == total_pairs - 1) tile_ranges[cur * 2 + 1] = (int32_t)total_pairs;
+    if (keys_sorted)
+        keys_sorted[i] = ((uint64_t)cur << 32) | (uint64_t)__float_as_uint(depths[pidx[i]]);
+}
+
+template <bool SRC_DEPTH>
+int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t count, int shift, int bits,
+               const SortWs& ws, uint32_t* kout, uint32_t* vout, hipStream_t st) {
+    const uint32_t nblk = nblocks_for(count, CHUNK);
+    const uint32_t mask = (1u << bits) - 1u;
+    hipLaunchKernelGGL((k_radix_hist<SRC_DEPTH>), dim3(nblk), dim3(CUGS_BLOCK), 0, st, kin, count, shift,
+                       mask, ws.hist, nblk);
+    CUGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, ws.hist, nblk, ws.tot);
+    CUGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_radix_scatter<SRC_DEPTH>), dim3(nblk), dim3(CUGS_BLOCK), 0, st, kin, vin, count,
+                       shift, mask, ws.hist, ws.tot, nblk, kout, vout);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
+
+int tile_bits(int tiles) {
+    int b = 1;
+    while ((1 << b) < tiles) ++b;
+    return b;
+}
+
+}  // namespace
+
+extern "C" size_t cugs_sort_workspace_bytes(int64_t n, int64_t max_pairs, int width, int height) {
+    (void)width; (void)height;
+    if (n < 0 || max_pairs < 0) return 0;
+    return carve(nullptr, n, max_pairs).bytes;
+}
+
+extern "C" int cugs_sort_count_pairs(int64_t n, const int32_t* tiles_touched, void* workspace,
+                                     size_t workspace_bytes, int64_t* total_pairs_host, void* stream) {
+    if (n < 0 || !total_pairs_host) return CUGS_EINVAL;
+    *total_pairs_host = 0;
+    if (n == 0) return 0;
+    if (!tiles_touched || !workspace) return CUGS_EINVAL;
+    if (workspace_bytes < 256) return CUGS_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned long long* total = static_cast<unsigned long long*>(workspace);
+    CUGS_RETURN_IF_HIP(hipMemsetAsync(total, 0, sizeof(unsigned long long), st));
+    const int64_t want = (n + CUGS_BLOCK - 1) / CUGS_BLOCK;
+    const int grid = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_sum_tiles, dim3(grid), dim3(CUGS_BLOCK), 0, st, n, tiles_touched, total);
+    CUGS_LAUNCH_CHECK();
+    unsigned long long host_total = 0;
+    CUGS_RETURN_IF_HIP(hipMemcpyAsync(&host_total, total, sizeof(host_total), hipMemcpyDeviceToHost, st));
+    CUGS_RETURN_IF_HIP(hipStreamSynchronize(st));
+    if (host_total > 2147483647ull) return CUGS_EOVERFLOW;   // the reference indexes pairs with int
+    *total_pairs_host = (int64_t)host_total;
+    return 0;
+}
+
+extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* means_2d,
+                               const float* depths, const int32_t* radii,
+                               const int32_t* tiles_touched, int width, int height, void* workspace,
+                               size_t workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                               int32_t* tile_ranges, void* stream) {
+    if (n < 0 || total_pairs < 0 || width < 0 || height < 0 || !tile_ranges) return CUGS_EINVAL;
+    if (n > 2147483647ll || total_pairs > 2147483647ll) return CUGS_EOVERFLOW;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
+    const int tiles = ntx * nty;
+    if (tiles > 0)   // untouched tiles stay {0,0} (sorting.cu:216)
+        CUGS_RETURN_IF_HIP(hipMemsetAsync(tile_ranges, 0, sizeof(int32_t) * 2 * (size_t)tiles, st));
+    if (n == 0 || total_pairs == 0 || tiles == 0) return 0;      // sorting.cu:133-139,154-160
+    if (!means_2d || !depths || !radii || !tiles_touched || !values_sorted || !workspace) return CUGS_EINVAL;
+    SortWs ws = carve(workspace, n, total_pairs);
+    if (workspace_bytes < ws.bytes) return CUGS_EWORKSPACE;
+
+    // (1) stable sort of the Gaussians by depth bits (positive floats order as unsigned ints)
+    const uint32_t un = (uint32_t)n, up = (uint32_t)total_pairs;
+    const uint32_t* dbits = reinterpret_cast<const uint32_t*>(depths);
+    int rc;
+    if ((rc = radix_pass<true>(dbits, nullptr, un, 0, 8, ws, ws.dkey[0], ws.dval[0], st))) return rc;
+    if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 8, 8, ws, ws.dkey[1], ws.dval[1], st))) return rc;
+    if ((rc = radix_pass<false>(ws.dkey[1], ws.dval[1], un, 16, 8, ws, ws.dkey[0], ws.dval[0], st))) return rc;
+    if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 24, 8, ws, ws.dkey[1], ws.dval[1], st))) return rc;
+    const uint32_t* order = ws.dval[1];
+
+    // (2) pairs in depth order
+    const uint32_t nfill = nblocks_for(n, FILL_CHUNK);
+    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, order, tiles_touched,
+                       ws.blocksum);
+    CUGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(CUGS_BLOCK), 0, st, ws.blocksum, nfill);
+    CUGS_LAUNCH_CHECK();
+
+    // (3) stable sort by tile id: choose the buffers so that the last pass lands in values_sorted
+    const int bits = tile_bits(tiles);
+    const int npass = (bits + 7) / 8;
+    const int per = (bits + npass - 1) / npass;
+    uint32_t* vals_final = reinterpret_cast<uint32_t*>(values_sorted);
+    // pass p reads (tk[p&1], tv_in) and writes (tk[(p+1)&1], tv_out)
+    uint32_t* tk[2] = {ws.ptile[0], ws.ptile[1]};
+    uint32_t* tv[2] = {ws.pidx[0], ws.pidx[1]};
+    hipLaunchKernelGGL(k_fill_pairs, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, up, order, tiles_touched,
+                       means_2d, radii, width, height, ntx, nty, ws.blocksum, tk[0], tv[0]);
+    CUGS_LAUNCH_CHECK();
+    int cur = 0;
+    for (int p = 0; p < npass; ++p) {
+        const int shift = p * per;
+        const int b = (bits - shift) < per ? (bits - shift) : per;
+        uint32_t* vout = (p == npass - 1) ? vals_final : tv[cur ^ 1];
+        if ((rc = radix_pass<false>(tk[cur], tv[cur], up, shift, b, ws, tk[cur ^ 1], vout, st))) return rc;
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_tile_ranges, dim3(nblocks_for(total_pairs, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st,
+                       up, tk[cur], values_sorted, depths, tile_ranges, keys_sorted);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,299 @@
+"""Host-side mirror of the reference's rasterizer operator surface over the C ABI.
+
+Same names, argument meaning and error behaviour as namespace cugs (file:line in the reference's src/):
+  project_gaussians          rasterizer/projection.hpp:39      (projection.cu:195-289)
+  sort_gaussians             rasterizer/sorting.hpp:41         (sorting.cu:115-227)
+  rasterize_forward          rasterizer/forward.hpp:41         (forward.cu:180-240)
+  rasterize_backward         rasterizer/backward.hpp:39        (backward.cu:239-306)
+  project_backward           rasterizer/projection_backward.hpp:44 (projection_backward.cu:253-344)
+  evaluate_sh_cuda           core/sh.hpp:29                    (sh.cu:81-123)
+  evaluate_sh_backward_cuda  core/sh_backward.hpp:25           (sh_backward.cu:114-156)
+  render / render_backward   rasterizer/rasterizer.hpp:57,88   (rasterizer.cpp:22-186)
+
+PyTorch is plumbing only: it owns device memory and the stream.  Every computation is a call
+into libcugs_hip.so; a TORCH_CHECK in the reference is a RuntimeError here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+from .types import (BackwardOutput, CameraInfo, ForwardOutput, GaussianModel, ProjectionBackwardOutput,
+                    ProjectionOutput, RasterizeBackwardOutput, RenderOutput, RenderSettings,
+                    SortingOutput, K_TILE_SIZE)
+
+
+def _torch_check(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(msg)          # c10::Error in the reference
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None or t.numel() == 0 else t.data_ptr())
+
+
+def _stream(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """`.contiguous().to(kFloat32)` as the launchers do (projection.cu:240-243)."""
+    return t.contiguous().to(torch.float32)
+
+
+_workspaces: Dict[torch.device, torch.Tensor] = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Caller-owned scratch for the sort: grown on demand, reused across calls (the reference
+    allocates CUB temp storage on every call, sorting.cu:198-200)."""
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+# --------------------------------------------------------------------------------------
+# stage functions
+# --------------------------------------------------------------------------------------
+def project_gaussians(positions: torch.Tensor, rotations: torch.Tensor, scales: torch.Tensor,
+                      opacities: torch.Tensor, sh_coeffs: torch.Tensor, camera: CameraInfo,
+                      active_sh_degree: int, scale_modifier: float = 1.0) -> ProjectionOutput:
+    _torch_check(positions.is_cuda, "positions must be on CUDA")
+    _torch_check(positions.dim() == 2 and positions.shape[1] == 3, "positions must be [N, 3]")
+    n = int(positions.shape[0])
+    dev = positions.device
+    f = dict(dtype=torch.float32, device=dev)
+    i = dict(dtype=torch.int32, device=dev)
+    means_2d = torch.empty((n, 2), **f)
+    depths = torch.empty((n,), **f)
+    cov_2d_inv = torch.empty((n, 3), **f)
+    radii = torch.empty((n,), **i)
+    tiles_touched = torch.empty((n,), **i)
+    opacities_act = torch.empty((n,), **f)
+    rgb = torch.empty((n, 3), **f)
+    packed = torch.empty((n, _lib.PACKED_STRIDE), **f)
+    if n == 0:
+        return ProjectionOutput(means_2d, depths, cov_2d_inv, radii, tiles_touched, rgb, opacities_act, packed)
+    _torch_check(sh_coeffs.dim() == 3 and sh_coeffs.shape[1] == 3 and sh_coeffs.shape[0] == n,
+                 "sh_coeffs must be [N, 3, C]")
+    num_coeffs = int(sh_coeffs.shape[2])
+    _torch_check(0 <= active_sh_degree <= 3, f"SH degree must be 0..3, got {active_sh_degree}")
+    _torch_check((active_sh_degree + 1) ** 2 <= num_coeffs,
+                 f"Need at least {(active_sh_degree + 1) ** 2} coefficients for degree {active_sh_degree}")
+    pos_c, rot_c, scl_c, opa_c, sh_c = map(_f32c, (positions, rotations, scales, opacities, sh_coeffs))
+    cam = camera.to_abi()
+    check(lib.cugs_project_forward(n, num_coeffs, int(active_sh_degree), _ptr(pos_c), _ptr(rot_c), _ptr(scl_c),
+                                   _ptr(opa_c), _ptr(sh_c), C.byref(cam), float(scale_modifier),
+                                   _ptr(means_2d), _ptr(depths), _ptr(cov_2d_inv), _ptr(radii),
+                                   _ptr(tiles_touched), _ptr(opacities_act), _ptr(rgb), _ptr(packed),
+                                   _stream(dev)), "cugs_project_forward")
+    return ProjectionOutput(means_2d, depths, cov_2d_inv, radii, tiles_touched, rgb, opacities_act, packed)
+
+
+def evaluate_sh_cuda(degree: int, sh_coeffs: torch.Tensor, directions: torch.Tensor) -> torch.Tensor:
+    _torch_check(0 <= degree <= 3, f"SH degree must be 0..3, got {degree}")
+    _torch_check(sh_coeffs.is_cuda, "sh_coeffs must be on CUDA device")
+    _torch_check(directions.is_cuda, "directions must be on CUDA device")
+    _torch_check(sh_coeffs.dim() == 3 and sh_coeffs.shape[1] == 3, "sh_coeffs must be [N, 3, C]")
+    _torch_check(directions.dim() == 2 and directions.shape[1] == 3, "directions must be [N, 3]")
+    _torch_check(sh_coeffs.shape[0] == directions.shape[0], "Batch size mismatch")
+    num_coeffs = int(sh_coeffs.shape[2])
+    _torch_check(num_coeffs >= (degree + 1) ** 2,
+                 f"Need at least {(degree + 1) ** 2} coefficients for degree {degree}")
+    n = int(sh_coeffs.shape[0])
+    coeffs, dirs = _f32c(sh_coeffs), _f32c(directions)
+    out = torch.empty((n, 3), dtype=torch.float32, device=sh_coeffs.device)
+    if n == 0:
+        return out
+    check(lib.cugs_evaluate_sh(int(degree), n, num_coeffs, _ptr(coeffs), _ptr(dirs), _ptr(out),
+                               _stream(out.device)), "cugs_evaluate_sh")
+    return out
+
+
+def evaluate_sh_backward_cuda(degree: int, sh_coeffs: torch.Tensor, directions: torch.Tensor,
+                              dL_dcolor: torch.Tensor) -> torch.Tensor:
+    _torch_check(0 <= degree <= 3, f"SH degree must be 0..3, got {degree}")
+    _torch_check(sh_coeffs.is_cuda, "sh_coeffs must be on CUDA device")
+    _torch_check(directions.is_cuda, "directions must be on CUDA device")
+    _torch_check(dL_dcolor.is_cuda, "dL_dcolor must be on CUDA device")
+    _torch_check(sh_coeffs.dim() == 3 and sh_coeffs.shape[1] == 3, "sh_coeffs must be [N, 3, C]")
+    _torch_check(directions.dim() == 2 and directions.shape[1] == 3, "directions must be [N, 3]")
+    _torch_check(dL_dcolor.dim() == 2 and dL_dcolor.shape[1] == 3, "dL_dcolor must be [N, 3]")
+    n, num_coeffs = int(sh_coeffs.shape[0]), int(sh_coeffs.shape[2])
+    _torch_check(num_coeffs >= (degree + 1) ** 2, "not enough SH coefficients for the degree")
+    coeffs, dirs, g = _f32c(sh_coeffs), _f32c(directions), _f32c(dL_dcolor)
+    out = torch.empty_like(coeffs)
+    if n == 0:
+        return out
+    check(lib.cugs_evaluate_sh_backward(int(degree), n, num_coeffs, _ptr(coeffs), _ptr(dirs), _ptr(g),
+                                        _ptr(out), _stream(out.device)), "cugs_evaluate_sh_backward")
+    return out
+
+
+def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Tensor,
+                   tiles_touched: torch.Tensor, img_w: int, img_h: int, want_keys: bool = True) -> SortingOutput:
+    _torch_check(means_2d.is_cuda, "means_2d must be on CUDA")
+    n = int(means_2d.shape[0])
+    dev = means_2d.device
+    ntx = (img_w + K_TILE_SIZE - 1) // K_TILE_SIZE
+    nty = (img_h + K_TILE_SIZE - 1) // K_TILE_SIZE
+    num_tiles = ntx * nty
+    i32 = dict(dtype=torch.int32, device=dev)
+    tile_ranges = torch.empty((num_tiles, 2), **i32)
+    st = _stream(dev)
+    total = C.c_int64(0)
+    tiles_c = tiles_touched.contiguous().to(torch.int32)
+    if n > 0:
+        ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n, 0, img_w, img_h))
+        check(lib.cugs_sort_count_pairs(n, _ptr(tiles_c), _ptr(ws), ws.numel(), C.byref(total), st),
+              "cugs_sort_count_pairs")
+    p = int(total.value)
+    keys = torch.empty((p if want_keys else 0,), dtype=torch.int64, device=dev)
+    vals = torch.empty((p,), **i32)
+    if num_tiles > 0:
+        ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n, p, img_w, img_h))
+        check(lib.cugs_sort_pairs(n, p, _ptr(means_2d.contiguous()), _ptr(depths.contiguous()),
+                                  _ptr(radii.contiguous()), _ptr(tiles_c), int(img_w), int(img_h), _ptr(ws),
+                                  ws.numel(), _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals),
+                                  _ptr(tile_ranges), st), "cugs_sort_pairs")
+    return SortingOutput(keys, vals, tile_ranges, p)
+
+
+def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: torch.Tensor,
+                      opacities: torch.Tensor, tile_ranges: torch.Tensor, gaussian_indices: torch.Tensor,
+                      img_w: int, img_h: int, background: Sequence[float],
+                      packed: Optional[torch.Tensor] = None) -> ForwardOutput:
+    _torch_check(means_2d.is_cuda, "means_2d must be on CUDA")
+    dev = means_2d.device
+    color = torch.empty((img_h, img_w, 3), dtype=torch.float32, device=dev)
+    final_T = torch.empty((img_h, img_w), dtype=torch.float32, device=dev)
+    n_contrib = torch.empty((img_h, img_w), dtype=torch.int32, device=dev)
+    if img_w == 0 or img_h == 0:
+        return ForwardOutput(color, final_T, n_contrib)
+    bg = (C.c_float * 3)(*[float(b) for b in background])
+    check(lib.cugs_rasterize_forward(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
+                                     _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
+                                     _ptr(cov_2d_inv.contiguous()), _ptr(rgb.contiguous()),
+                                     _ptr(opacities.contiguous()), _ptr(packed), _ptr(color), _ptr(final_T),
+                                     _ptr(n_contrib), _stream(dev)), "cugs_rasterize_forward")
+    return ForwardOutput(color, final_T, n_contrib)
+
+
+def rasterize_backward(dL_dcolor: torch.Tensor, means_2d: torch.Tensor, cov_2d_inv: torch.Tensor,
+                       rgb: torch.Tensor, opacities: torch.Tensor, tile_ranges: torch.Tensor,
+                       gaussian_indices: torch.Tensor, final_T: torch.Tensor, n_contrib: torch.Tensor,
+                       img_w: int, img_h: int, background: Sequence[float], n_gaussians: int,
+                       packed: Optional[torch.Tensor] = None, unpack: bool = True) -> RasterizeBackwardOutput:
+    _torch_check(dL_dcolor.is_cuda, "dL_dcolor must be on CUDA")
+    dev = dL_dcolor.device
+    n = int(n_gaussians)
+    f = dict(dtype=torch.float32, device=dev)
+    accum = torch.empty((n, _lib.GRAD_STRIDE), **f)
+    if unpack:
+        d_rgb, d_opa = torch.empty((n, 3), **f), torch.empty((n,), **f)
+        d_means, d_cov = torch.empty((n, 2), **f), torch.empty((n, 3), **f)
+    else:
+        d_rgb = d_opa = d_means = d_cov = None
+    if n > 0:
+        bg = (C.c_float * 3)(*[float(b) for b in background])
+        check(lib.cugs_rasterize_backward(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
+                                          _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
+                                          _ptr(cov_2d_inv.contiguous()), _ptr(rgb.contiguous()),
+                                          _ptr(opacities.contiguous()), _ptr(packed),
+                                          _ptr(dL_dcolor.contiguous()), _ptr(final_T.contiguous()),
+                                          _ptr(n_contrib.contiguous()), n, _ptr(accum), _ptr(d_rgb), _ptr(d_opa),
+                                          _ptr(d_means), _ptr(d_cov), _stream(dev)), "cugs_rasterize_backward")
+    return RasterizeBackwardOutput(d_rgb, d_opa, d_means, d_cov, accum)
+
+
+def project_backward(dL_dmeans_2d: Optional[torch.Tensor], dL_dcov_2d_inv: Optional[torch.Tensor],
+                     dL_drgb: Optional[torch.Tensor], dL_dopacity_act: Optional[torch.Tensor],
+                     positions: torch.Tensor, rotations: torch.Tensor, scales: torch.Tensor,
+                     opacities: torch.Tensor, sh_coeffs: torch.Tensor, radii: torch.Tensor,
+                     camera: CameraInfo, active_sh_degree: int, scale_modifier: float = 1.0,
+                     grad_accum: Optional[torch.Tensor] = None, rgb_clamped: Optional[torch.Tensor] = None,
+                     dL_dmeans_2d_out: Optional[torch.Tensor] = None) -> ProjectionBackwardOutput:
+    _torch_check(positions.is_cuda, "positions must be on CUDA")
+    n = int(positions.shape[0])
+    dev = positions.device
+    f = dict(dtype=torch.float32, device=dev)
+    d_pos, d_rot = torch.empty((n, 3), **f), torch.empty((n, 4), **f)
+    d_scl, d_opa = torch.empty((n, 3), **f), torch.empty((n, 1), **f)
+    sh_c = _f32c(sh_coeffs)
+    d_sh = torch.empty_like(sh_c)
+    if n == 0:
+        return ProjectionBackwardOutput(d_pos, d_rot, d_scl, d_opa, d_sh)
+    pos_c, rot_c, scl_c, opa_c = map(_f32c, (positions, rotations, scales, opacities))
+    cam = camera.to_abi()
+    cont = lambda t: None if t is None else t.contiguous()
+    check(lib.cugs_project_backward(n, int(sh_c.shape[2]), int(active_sh_degree), _ptr(pos_c), _ptr(rot_c),
+                                    _ptr(scl_c), _ptr(opa_c), _ptr(sh_c), _ptr(radii.contiguous()),
+                                    _ptr(cont(rgb_clamped)), C.byref(cam), float(scale_modifier),
+                                    _ptr(cont(grad_accum)), _ptr(cont(dL_dmeans_2d)), _ptr(cont(dL_dcov_2d_inv)),
+                                    _ptr(cont(dL_drgb)), _ptr(cont(dL_dopacity_act)), _ptr(d_pos), _ptr(d_rot),
+                                    _ptr(d_scl), _ptr(d_opa), _ptr(d_sh), _ptr(dL_dmeans_2d_out), _stream(dev)),
+          "cugs_project_backward")
+    return ProjectionBackwardOutput(d_pos, d_rot, d_scl, d_opa, d_sh)
+
+
+# --------------------------------------------------------------------------------------
+# render / render_backward (rasterizer.cpp:22-186)
+# --------------------------------------------------------------------------------------
+def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings) -> RenderOutput:
+    _torch_check(model.is_valid(), "GaussianModel is not valid")
+    _torch_check(model.positions.is_cuda, "GaussianModel must be on CUDA device")
+    n = model.num_gaussians()
+    dev = model.positions.device
+    f = dict(dtype=torch.float32, device=dev)
+    i = dict(dtype=torch.int32, device=dev)
+    if n == 0:                                           # rasterizer.cpp:36-55
+        color = torch.empty((camera.height, camera.width, 3), **f)
+        for ch in range(3):
+            color[..., ch] = float(settings.background[ch])
+        return RenderOutput(color, torch.ones((camera.height, camera.width), **f),
+                            torch.zeros((camera.height, camera.width), **i), torch.empty((0, 2), **f),
+                            torch.empty((0,), **f), torch.empty((0, 3), **f), torch.empty((0,), **i),
+                            torch.empty((0, 3), **f), torch.empty((0,), **f), torch.empty((0,), **i),
+                            torch.empty((0, 2), **i))
+    active_degree = min(int(settings.active_sh_degree), model.max_sh_degree())
+    proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs,
+                             camera, active_degree, settings.scale_modifier)
+    srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, camera.width,
+                         camera.height, want_keys=False)
+    fwd = rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
+                            srt.gaussian_values_sorted, camera.width, camera.height, settings.background,
+                            packed=proj.packed)
+    return RenderOutput(fwd.color, fwd.final_T, fwd.n_contrib, proj.means_2d, proj.depths, proj.cov_2d_inv,
+                        proj.radii, proj.rgb, proj.opacities_act, srt.gaussian_values_sorted, srt.tile_ranges,
+                        packed=proj.packed, total_pairs=srt.total_pairs)
+
+
+def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: GaussianModel,
+                    camera: CameraInfo, settings: RenderSettings) -> BackwardOutput:
+    _torch_check(dL_dcolor.is_cuda, "dL_dcolor must be on CUDA device")
+    _torch_check(dL_dcolor.dim() == 3 and dL_dcolor.shape[2] == 3, "dL_dcolor must be [H, W, 3]")
+    n = model.num_gaussians()
+    dev = dL_dcolor.device
+    f = dict(dtype=torch.float32, device=dev)
+    if n == 0:                                           # rasterizer.cpp:130-139
+        return BackwardOutput(torch.zeros((0, 3), **f), torch.zeros((0, 4), **f), torch.zeros((0, 3), **f),
+                              torch.zeros((0, 1), **f), torch.zeros_like(model.sh_coeffs),
+                              torch.zeros((0, 2), **f))
+    active_degree = min(int(settings.active_sh_degree), model.max_sh_degree())
+    rb = rasterize_backward(dL_dcolor, render_out.means_2d, render_out.cov_2d_inv, render_out.rgb,
+                            render_out.opacities_act, render_out.tile_ranges, render_out.gaussian_indices,
+                            render_out.final_T, render_out.n_contrib, camera.width, camera.height,
+                            settings.background, n, packed=render_out.packed, unpack=False)
+    d_means_2d = torch.empty((n, 2), **f)
+    pb = project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
+                          model.opacities, model.sh_coeffs, render_out.radii, camera, active_degree,
+                          settings.scale_modifier, grad_accum=rb.grad_accum, rgb_clamped=render_out.rgb,
+                          dL_dmeans_2d_out=d_means_2d)
+    return BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
+                          pb.dL_dsh_coeffs, d_means_2d)

@@ -1,0 +1,177 @@
+/* cugs_hip.h — C ABI of libcugs_hip.so: the MI355X-native differentiable Gaussian-splat
+ * rasterizer + fused Adam, as a drop-in for the hot path of
+ * Artemarius/cuda-gaussian-splatting (namespace cugs).
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless its name
+ *     ends in _host; arrays use the reference's layouts and dtypes (fp32 / int32, row-major);
+ *   - the callee allocates nothing: outputs and scratch are caller-owned; outputs the
+ *     reference zero-fills (torch::zeros) are fully written by the kernels;
+ *   - every function is stream-ordered on `stream` (a hipStream_t passed as void*; NULL =
+ *     the null stream), re-entrant, and keeps no global state;
+ *   - return value: 0 on success, a positive hipError_t from the HIP runtime, or a negative
+ *     CUGS_E* argument error.  Nothing throws or aborts across this boundary; the adapter
+ *     turns non-zero into std::runtime_error the way CUDA_CHECK does (utils/cuda_utils.cuh:12-20);
+ *   - only launch errors are reported (no device sync), as in the reference
+ *     (projection.cu:267); cugs_sort_count_pairs is the one blocking call (sorting.cu:146).
+ *
+ * Citations are file:line in the reference's src/ tree.
+ */
+#ifndef CUGS_HIP_H
+#define CUGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUGS_TILE 16                 /* rasterizer/sorting.hpp:16 kTileSize */
+#define CUGS_PACKED_STRIDE 12        /* floats per packed projected-Gaussian record */
+#define CUGS_GRAD_STRIDE 16          /* floats per packed 2-D gradient accumulator row */
+
+#define CUGS_EINVAL (-1)             /* bad size / degree / null pointer */
+#define CUGS_EALIGN (-2)             /* a buffer that must be 16-byte aligned is not */
+#define CUGS_EOVERFLOW (-3)          /* pair count does not fit int32 (the reference's index type) */
+#define CUGS_EWORKSPACE (-4)         /* workspace too small for (n, total_pairs) */
+
+/* POD camera: what the adapter derives from cugs::CameraInfo (core/types.hpp:78-109).
+ * view = row-major 4x4 world-to-camera, the float[16] built at projection.cu:228-233;
+ * cam_center = -R^T t (types.hpp:98-100), the 3 floats uploaded at projection.cu:273-275. */
+typedef struct cugs_camera {
+    float view[16];
+    float fx, fy, cx, cy;
+    int32_t width, height;
+    float cam_center[3];
+    float reserved;
+} cugs_camera;
+
+const char* cugs_version(void);
+/* Message for a return code of this library (hipGetErrorString for positive codes). */
+const char* cugs_error_string(int code);
+
+/* ---- a3+a4: project_gaussians (projection.cu:195-289) -------------------------------
+ * One launch: k_project_gaussians (projection.cu:55-189) + view directions
+ * (projection.cu:273-280) + k_evaluate_sh (core/sh.cu:19-79) + clamp_min(0) (projection.cu:284).
+ * positions [n,3], rotations [n,4] (wxyz), scales [n,3] (log), opacities [n] (logit),
+ * sh_coeffs [n,3,num_coeffs]; active_degree in 0..3 with (active_degree+1)^2 <= num_coeffs.
+ * Outputs: means_2d [n,2], depths [n], cov_2d_inv [n,3], radii [n] i32, tiles_touched [n] i32,
+ * opacities_act [n], rgb [n,3] (clamped).  `packed` ([n,CUGS_PACKED_STRIDE] floats, 16-byte
+ * aligned) is optional scratch consumed by cugs_rasterize_*; pass NULL to skip it. */
+int cugs_project_forward(int64_t n, int num_coeffs, int active_degree,
+                         const float* positions, const float* rotations, const float* scales,
+                         const float* opacities, const float* sh_coeffs,
+                         const cugs_camera* camera_host, float scale_modifier,
+                         float* means_2d, float* depths, float* cov_2d_inv, int32_t* radii,
+                         int32_t* tiles_touched, float* opacities_act, float* rgb,
+                         float* packed, void* stream);
+
+/* ---- a4: evaluate_sh_cuda (core/sh.cu:81-123), output NOT clamped ------------------- */
+int cugs_evaluate_sh(int degree, int64_t n, int num_coeffs, const float* sh_coeffs,
+                     const float* directions, float* out_rgb, void* stream);
+
+/* ---- a9: evaluate_sh_backward_cuda (core/sh_backward.cu:114-156) -------------------- */
+int cugs_evaluate_sh_backward(int degree, int64_t n, int num_coeffs, const float* sh_coeffs,
+                              const float* directions, const float* dL_dcolor,
+                              float* dL_dsh, void* stream);
+
+/* Fills `packed` from the reference-layout projection outputs, for callers that did not get
+ * it from cugs_project_forward (e.g. tests that drive rasterize_forward directly). */
+int cugs_pack_projected(int64_t n, const float* means_2d, const float* cov_2d_inv,
+                        const float* rgb, const float* opacities_act, float* packed,
+                        void* stream);
+
+/* ---- a5: sort_gaussians (sorting.cu:115-227) ----------------------------------------
+ * Replaces the cumsum + .item() (sorting.cu:145-146), k_fill_sort_pairs (:30-72),
+ * cub::DeviceRadixSort::SortPairs (:191-210; contract: ascending, stable, full 64-bit key)
+ * and k_compute_tile_ranges (:82-109).  The workspace query replaces CUB's two-call
+ * temp-storage idiom (:191-198).  max_pairs bounds total_pairs. */
+size_t cugs_sort_workspace_bytes(int64_t n, int64_t max_pairs, int width, int height);
+
+/* total_pairs = sum(tiles_touched).  BLOCKS until the value is on the host (the reference's
+ * one forced sync).  `workspace` needs cugs_sort_workspace_bytes(n, 0, w, h) bytes. */
+int cugs_sort_count_pairs(int64_t n, const int32_t* tiles_touched, void* workspace,
+                          size_t workspace_bytes, int64_t* total_pairs_host, void* stream);
+
+/* keys_sorted [P] u64 (tile_id<<32 | depth bits; may be NULL), values_sorted [P] i32,
+ * tile_ranges [tiles,2] i32 ({0,0} for untouched tiles, sorting.cu:216). */
+int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* means_2d, const float* depths,
+                    const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                    void* workspace, size_t workspace_bytes, uint64_t* keys_sorted,
+                    int32_t* values_sorted, int32_t* tile_ranges, void* stream);
+
+/* ---- a6: rasterize_forward (forward.cu:180-240, kernel :48-174) ---------------------
+ * out_color [H,W,3], out_final_T [H,W], out_n_contrib [H,W] i32.  `packed` may be NULL
+ * (records are then gathered from the four reference-layout arrays). */
+int cugs_rasterize_forward(int width, int height, const float background_host[3],
+                           const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                           const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                           const float* opacities_act, const float* packed,
+                           float* out_color, float* out_final_T, int32_t* out_n_contrib,
+                           void* stream);
+
+/* ---- a7: rasterize_backward (backward.cu:239-306, kernel :31-233) -------------------
+ * grad_accum: [n,CUGS_GRAD_STRIDE] floats, 64-byte aligned scratch (zeroed by the callee);
+ * row = {dL_drgb[3], dL_dopacity_act, dL_dmeans_2d[2], dL_dcov_2d_inv[3], 0...}.
+ * The four reference-layout outputs (dL_drgb [n,3], dL_dopacity_act [n], dL_dmeans_2d [n,2],
+ * dL_dcov_2d_inv [n,3]) are written from it when non-NULL (all four or none). */
+int cugs_rasterize_backward(int width, int height, const float background_host[3],
+                            const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                            const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                            const float* opacities_act, const float* packed,
+                            const float* dL_dcolor, const float* final_T,
+                            const int32_t* n_contrib, int64_t n, float* grad_accum,
+                            float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
+                            float* dL_dcov_2d_inv, void* stream);
+
+/* ---- a8+a9: project_backward (projection_backward.cu:253-344, kernel :26-247) -------
+ * One launch: k_project_backward + directions + k_evaluate_sh_backward.  The incoming 2-D
+ * gradients come either from grad_accum (packed rows, preferred) or, when grad_accum is
+ * NULL, from the four reference-layout arrays.  rgb_clamped (the forward's rgb) supplies
+ * the ReLU gate (raw > 0 <=> clamped > 0, sh_backward.cu:92-100); when NULL the gate is
+ * recomputed from sh_coeffs as the reference does.  dL_dmeans_2d_out ([n,2], may be NULL)
+ * receives BackwardOutput::dL_dmeans_2d (rasterizer.cpp:184) when grad_accum is used. */
+int cugs_project_backward(int64_t n, int num_coeffs, int active_degree,
+                          const float* positions, const float* rotations, const float* scales,
+                          const float* opacities, const float* sh_coeffs, const int32_t* radii,
+                          const float* rgb_clamped, const cugs_camera* camera_host,
+                          float scale_modifier, const float* grad_accum,
+                          const float* dL_dmeans_2d, const float* dL_dcov_2d_inv,
+                          const float* dL_drgb, const float* dL_dopacity_act,
+                          float* dL_dpositions, float* dL_drotations, float* dL_dscales,
+                          float* dL_dopacities, float* dL_dsh_coeffs, float* dL_dmeans_2d_out,
+                          void* stream);
+
+/* ---- a11: FusedAdam (optimizer/fused_adam.cu:44-76,140-219) -------------------------
+ * bc1 = 1/(1-beta1^t), bc2 = 1/(1-beta2^t) computed in double on the host, then float
+ * (fused_adam.cu:145-148,161-162). */
+void cugs_adam_bias_correction(float beta1, float beta2, int step, float* bc1_host,
+                               float* bc2_host);
+
+/* One parameter tensor (k_fused_adam, fused_adam.cu:44-76): in-place on param, m, v. */
+int cugs_fused_adam(float* param, const float* grad, float* m, float* v, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float bc1, float bc2, void* stream);
+
+typedef struct cugs_adam_group {
+    float* param;
+    const float* grad;     /* NULL: group skipped (fused_adam.cu:156 "if (!grads_[i].defined())") */
+    float* m;
+    float* v;
+    int64_t n;
+    float lr;
+    float reserved;
+} cugs_adam_group;
+
+/* All parameter groups in ONE launch (the reference launches one kernel per group,
+ * fused_adam.cu:155-163).  ngroups <= 8. */
+int cugs_fused_adam_groups(const cugs_adam_group* groups_host, int ngroups, float beta1,
+                           float beta2, float eps, float bc1, float bc2, void* stream);
+
+/* Device properties the host side needs without linking the HIP runtime itself. */
+int cugs_device_count(int* count_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUGS_HIP_H */
