@@ -17,4 +17,4 @@ from .rasterizer import (evaluate_sh_backward_cuda, evaluate_sh_cuda, project_ba
                          sort_gaussians)
 from .fused_adam import (AdamConfig, FusedAdam, ParamGroup, PositionLRConfig,  # noqa: F401
                          active_sh_degree_for_step, lr_defaults, position_lr)
-from . import scene  # noqa: F401
+from . import parallel, scene  # noqa: F401

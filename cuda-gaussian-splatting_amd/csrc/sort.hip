@@ -110,13 +110,39 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_sum_tiles(int64_t n, const int32
     if (threadIdx.x == 0) atomicAdd(total, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
+// Reference quirk Q12: a splat whose tile rectangle is empty in both axes still has
+// tiles_touched = (negative) x (negative) > 0 (projection.cu:187-188); k_fill_sort_pairs writes
+// nothing for it and its reserved slots keep the zero-initialised (key 0, value 0) pairs
+// (sorting.cu:166-167), which sort to the front of tile 0.  Reproduced here by giving such a
+// Gaussian the depth key 0 (its pairs are emitted first) and emitting (tile 0, Gaussian 0).
+__device__ __forceinline__ bool fills_nothing(const float* __restrict__ means_2d, int radius, uint32_t idx,
+                                              int img_w, int img_h, int ntx, int nty) {
+    if (radius <= 0) return true;                                   // sorting.cu:44-45
+    const TileRect tr = tile_rect_of(means_2d[idx * 2 + 0], means_2d[idx * 2 + 1], radius, img_w, img_h,
+                                     ntx, nty);
+    return tr.x1 <= tr.x0 || tr.y1 <= tr.y0;
+}
+
+__global__ __launch_bounds__(CUGS_BLOCK) void k_depth_keys(uint32_t n, const float* __restrict__ depths,
+                                                           const float* __restrict__ means_2d,
+                                                           const int32_t* __restrict__ radii,
+                                                           const int32_t* __restrict__ tiles, int img_w,
+                                                           int img_h, int ntx, int nty,
+                                                           uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t key = __float_as_uint(depths[i]);
+    if (tiles[i] > 0 && fills_nothing(means_2d, radii[i], i, img_w, img_h, ntx, nty)) key = 0u;
+    keys[i] = key;
+}
+
 // ------------------------------------------------------------------------------------
-// One radix pass = hist + row scan + scatter.  SRC_DEPTH: first pass of the depth sort reads
-// the float depths directly and generates the index on the fly (no init kernel).
+// One radix pass = hist + row scan + scatter.  SRC_DEPTH: first pass of the depth sort, which
+// generates the Gaussian index on the fly instead of reading a value array.
 // ------------------------------------------------------------------------------------
 template <bool SRC_DEPTH>
 __device__ __forceinline__ uint32_t load_key(const uint32_t* __restrict__ keys, uint32_t i) {
-    return keys[i];   // float bits reinterpreted by the caller's pointer cast when SRC_DEPTH
+    return keys[i];
 }
 
 template <bool SRC_DEPTH>
@@ -259,7 +285,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     uint32_t n, uint32_t total_pairs, const uint32_t* __restrict__ order,
     const int32_t* __restrict__ tiles, const float* __restrict__ means_2d,
     const int32_t* __restrict__ radii, int img_w, int img_h, int ntx, int nty,
-    const uint32_t* __restrict__ blocksum, uint32_t* __restrict__ ptile, uint32_t* __restrict__ pidx) {
+    const uint32_t* __restrict__ blocksum, uint32_t* __restrict__ ptile, uint32_t* __restrict__ pidx,
+    uint32_t* __restrict__ zero_pairs) {
     __shared__ uint32_t s_tmp[4];
     uint32_t g[FILL_IPT], t[FILL_IPT], acc = 0;
 #pragma unroll
@@ -274,20 +301,26 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     for (int j = 0; j < FILL_IPT; ++j) {
         if (t[j] == 0) continue;
         const uint32_t idx = g[j];
-        const int radius = radii[idx];
-        if (radius <= 0) continue;                                  // sorting.cu:44-45
-        const TileRect tr = tile_rect_of(means_2d[idx * 2 + 0], means_2d[idx * 2 + 1], radius, img_w,
-                                         img_h, ntx, nty);
         uint32_t w = pos;
         const uint32_t end = min(pos + t[j], total_pairs);         // never write past the buffers
-        for (int ty = tr.y0; ty < tr.y1; ++ty)
-            for (int tx = tr.x0; tx < tr.x1; ++tx) {
-                if (w < end) {
-                    ptile[w] = (uint32_t)(ty * ntx + tx);
-                    pidx[w] = idx;
+        const int radius = radii[idx];
+        if (radius > 0) {                                           // sorting.cu:44-45
+            const TileRect tr = tile_rect_of(means_2d[idx * 2 + 0], means_2d[idx * 2 + 1], radius, img_w,
+                                             img_h, ntx, nty);
+            for (int ty = tr.y0; ty < tr.y1; ++ty)
+                for (int tx = tr.x0; tx < tr.x1; ++tx) {
+                    if (w < end) {
+                        ptile[w] = (uint32_t)(ty * ntx + tx);
+                        pidx[w] = idx;
+                    }
+                    ++w;
                 }
-                ++w;
-            }
+        }
+        if (w < end) atomicAdd(zero_pairs, end - w);               // rare
+        for (; w < end; ++w) {                                      // slots the reference leaves at zero (Q12)
+            ptile[w] = 0u;
+            pidx[w] = 0u;
+        }
         pos += t[j];
     }
 }
@@ -299,7 +332,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t total_pairs
                                                             const int32_t* __restrict__ pidx,
                                                             const float* __restrict__ depths,
                                                             int32_t* __restrict__ tile_ranges,
-                                                            uint64_t* __restrict__ keys_sorted) {
+                                                            uint64_t* __restrict__ keys_sorted,
+                                                            const uint32_t* __restrict__ zero_pairs) {
     const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
     if (i >= total_pairs) return;
     const uint32_t cur = ptile[i];
@@ -313,8 +347,9 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t total_pairs
         }
     }
     if (i == total_pairs - 1) tile_ranges[cur * 2 + 1] = (int32_t)total_pairs;
-    if (keys_sorted)
-        keys_sorted[i] = ((uint64_t)cur << 32) | (uint64_t)__float_as_uint(depths[pidx[i]]);
+    if (keys_sorted)   // Q12 pairs are the leading entries of tile 0 and carry depth bits 0
+        keys_sorted[i] = (i < *zero_pairs) ? 0ull
+                                            : (((uint64_t)cur << 32) | (uint64_t)__float_as_uint(depths[pidx[i]]));
 }
 
 template <bool SRC_DEPTH>
@@ -388,9 +423,13 @@ extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* mean
 
     // (1) stable sort of the Gaussians by depth bits (positive floats order as unsigned ints)
     const uint32_t un = (uint32_t)n, up = (uint32_t)total_pairs;
-    const uint32_t* dbits = reinterpret_cast<const uint32_t*>(depths);
+    uint32_t* zero_pairs = reinterpret_cast<uint32_t*>(ws.total) + 4;     // inside the first 256-byte slot
+    CUGS_RETURN_IF_HIP(hipMemsetAsync(zero_pairs, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_depth_keys, dim3(nblocks_for(n, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
+                       means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1]);
+    CUGS_LAUNCH_CHECK();
     int rc;
-    if ((rc = radix_pass<true>(dbits, nullptr, un, 0, 8, ws, ws.dkey[0], ws.dval[0], st))) return rc;
+    if ((rc = radix_pass<true>(ws.dkey[1], nullptr, un, 0, 8, ws, ws.dkey[0], ws.dval[0], st))) return rc;
     if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 8, 8, ws, ws.dkey[1], ws.dval[1], st))) return rc;
     if ((rc = radix_pass<false>(ws.dkey[1], ws.dval[1], un, 16, 8, ws, ws.dkey[0], ws.dval[0], st))) return rc;
     if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 24, 8, ws, ws.dkey[1], ws.dval[1], st))) return rc;
@@ -413,7 +452,7 @@ extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* mean
     uint32_t* tk[2] = {ws.ptile[0], ws.ptile[1]};
     uint32_t* tv[2] = {ws.pidx[0], ws.pidx[1]};
     hipLaunchKernelGGL(k_fill_pairs, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, up, order, tiles_touched,
-                       means_2d, radii, width, height, ntx, nty, ws.blocksum, tk[0], tv[0]);
+                       means_2d, radii, width, height, ntx, nty, ws.blocksum, tk[0], tv[0], zero_pairs);
     CUGS_LAUNCH_CHECK();
     int cur = 0;
     for (int p = 0; p < npass; ++p) {
@@ -424,7 +463,7 @@ extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* mean
         cur ^= 1;
     }
     hipLaunchKernelGGL(k_tile_ranges, dim3(nblocks_for(total_pairs, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st,
-                       up, tk[cur], values_sorted, depths, tile_ranges, keys_sorted);
+                       up, tk[cur], values_sorted, depths, tile_ranges, keys_sorted, zero_pairs);
     CUGS_LAUNCH_CHECK();
     return 0;
 }

@@ -367,7 +367,14 @@ static void stable_sort_pairs_u64(int64_t p, uint64_t* keys, int32_t* vals) {
 /* k_fill_sort_pairs (sorting.cu:30-72) in Gaussian-index order at the exclusive-scan
  * offsets (sorting.cu:149-152), SortPairs, then k_compute_tile_ranges (sorting.cu:82-109)
  * into a zero-filled [tiles,2] buffer (sorting.cu:216).  total_pairs must equal
- * orc_count_pairs().  Returns 0, or -1 when the fill does not produce total_pairs. */
+ * orc_count_pairs().
+ *
+ * Reference quirk kept (not in SURVEY's list): the unsorted key/value buffers
+ * are torch::zeros (sorting.cu:166-167) and a Gaussian whose tile rectangle is empty in BOTH
+ * axes has tiles_touched = (negative)*(negative) > 0 (projection.cu:187-188) while its fill
+ * loops write nothing.  Its reserved slots therefore keep key 0 / value 0: pairs
+ * (tile 0, depth bits 0, Gaussian 0) that sort to the very front of tile 0's list.
+ * Returns 0, or -1 if a fill would run past total_pairs (inconsistent caller input). */
 int orc_sort(int n, const float* means_2d, const float* depths, const int32_t* radii,
              const int32_t* tiles_touched, int img_w, int img_h, int64_t total_pairs,
              uint64_t* keys_sorted, int32_t* values_sorted, int32_t* tile_ranges) {
@@ -375,6 +382,8 @@ int orc_sort(int n, const float* means_2d, const float* depths, const int32_t* r
     int nty = (img_h + TILE - 1) / TILE;
     memset(tile_ranges, 0, sizeof(int32_t) * 2 * (size_t)ntx * (size_t)nty);
     if (n == 0 || total_pairs == 0) return 0;
+    memset(keys_sorted, 0, sizeof(uint64_t) * (size_t)total_pairs);      /* sorting.cu:166 */
+    memset(values_sorted, 0, sizeof(int32_t) * (size_t)total_pairs);     /* sorting.cu:167 */
 
     int64_t offset = 0;
     for (int idx = 0; idx < n; ++idx) {
@@ -394,9 +403,7 @@ int orc_sort(int n, const float* means_2d, const float* depths, const int32_t* r
                 values_sorted[write_pos] = idx;
                 write_pos++;
             }
-        if (write_pos != offset) return -1;
     }
-    if (offset != total_pairs) return -1;
 
     stable_sort_pairs_u64(total_pairs, keys_sorted, values_sorted);
 

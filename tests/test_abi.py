@@ -1,0 +1,84 @@
+"""The C-ABI shared library loads without a GPU, exports every function include/cugs_hip.h declares,
+and rejects bad arguments with its negative error codes (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "cugs_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cugs_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_functions_all_exported_and_bound(pkg):
+    names = _declared()
+    assert len(names) >= 16
+    lib = C.CDLL(pkg.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/cugs_hip.h but not exported"
+    from cugs_amd import _lib
+    assert sorted(_lib.SIGNATURES) == names            # the ctypes table covers exactly the header
+
+
+def test_version_and_error_strings(pkg):
+    from cugs_amd._lib import lib
+    assert "gfx950" in pkg.version()
+    assert lib.cugs_error_string(0) == b"success"
+    for code in (-1, -2, -3, -4):
+        assert lib.cugs_error_string(code).startswith(b"cugs:")
+
+
+def test_argument_validation_without_gpu(pkg):
+    from cugs_amd._lib import lib, Camera
+    cam = Camera()
+    null = C.c_void_p(0)
+    # degree out of range / too few coefficients / unsupported coefficient count -> CUGS_EINVAL
+    args = lambda n, c, d: (n, c, d, null, null, null, null, null, C.byref(cam), 1.0, null, null, null, null, null,
+                            null, null, null, null)
+    assert lib.cugs_project_forward(*args(10, 16, 4)) == -1
+    assert lib.cugs_project_forward(*args(10, 4, 2)) == -1
+    assert lib.cugs_project_forward(*args(10, 5, 1)) == -1
+    assert lib.cugs_project_forward(*args(10, 16, 3)) == -1          # null pointers with n > 0
+    assert lib.cugs_project_forward(*args(0, 16, 3)) == 0            # n == 0: nothing to do
+    assert lib.cugs_evaluate_sh(5, 1, 16, null, null, null, null) == -1
+    assert lib.cugs_evaluate_sh(2, 1, 4, null, null, null, null) == -1
+    assert lib.cugs_evaluate_sh(1, 0, 4, null, null, null, null) == 0
+    assert lib.cugs_fused_adam(null, null, null, null, 0, 0.1, 0.9, 0.999, 1e-15, 1.0, 1.0, null) == 0
+    assert lib.cugs_fused_adam(null, null, null, null, 8, 0.1, 0.9, 0.999, 1e-15, 1.0, 1.0, null) == -1
+    assert lib.cugs_sort_workspace_bytes(-1, 0, 16, 16) == 0
+    small, big = lib.cugs_sort_workspace_bytes(1000, 0, 64, 64), lib.cugs_sort_workspace_bytes(1000, 5000, 64, 64)
+    assert 0 < small < big
+    # misaligned accumulator -> CUGS_EALIGN
+    bg = (C.c_float * 3)(0, 0, 0)
+    assert lib.cugs_rasterize_backward(16, 16, bg, null, null, null, null, null, null, null, null, null, null, 4,
+                                       C.c_void_p(0x1004), null, null, null, null, null) == -2
+
+
+def test_bias_correction_matches_oracle(pkg, orc):
+    from cugs_amd._lib import lib
+    for step in (1, 2, 10, 1000, 30000):
+        a, b = C.c_float(), C.c_float()
+        lib.cugs_adam_bias_correction(0.9, 0.999, step, C.byref(a), C.byref(b))
+        assert (a.value, b.value) == orc.adam_bias_correction(0.9, 0.999, step)
+
+
+def test_missing_library_fails_loudly(pkg, tmp_path, monkeypatch):
+    """No fallback: with the .so absent the product package refuses to import."""
+    import importlib.util
+    import sys
+    from cugs_amd import _lib
+    src = os.path.dirname(_lib.__file__)
+    dst = tmp_path / "pkgcopy"
+    dst.mkdir()
+    for f in ("_lib.py",):
+        (dst / f).write_text(open(os.path.join(src, f)).read())
+    spec = importlib.util.spec_from_file_location("cugs_lib_copy", str(dst / "_lib.py"))
+    mod = importlib.util.module_from_spec(spec)
+    with pytest.raises(ImportError, match="no fallback"):
+        spec.loader.exec_module(mod)
+    sys.modules.pop("cugs_lib_copy", None)

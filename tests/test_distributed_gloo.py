@@ -1,0 +1,57 @@
+"""World-size-2 coverage of the data-parallel exchange step on CPU (gloo): the same
+allreduce_gradients() that bench.py runs over RCCL/xGMI, SUM semantics, dL_dmeans_2d untouched."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, c = 50, 16
+        g = torch.Generator().manual_seed(1000 + rank)
+        mk = lambda *s: torch.randn(*s, generator=g)
+        grads = pkg.BackwardOutput(mk(n, 3), mk(n, 4), mk(n, 3), mk(n, 1), mk(n, 3, c), mk(n, 2))
+        local = {f: getattr(grads, f).clone() for f in pkg.parallel.GRAD_FIELDS + ("dL_dmeans_2d",)}
+        works = pkg.parallel.allreduce_gradients(grads, async_op=True)
+        pkg.parallel.wait_all(works)
+        out = {f: getattr(grads, f).clone() for f in local}
+        views = [pkg.parallel.view_for_rank(s, rank, world, 8) for s in range(4)]
+        # numpy: pickled by value (torch tensors would travel as shared-memory handles)
+        q.put((rank, {k: v.numpy() for k, v in local.items()}, {k: v.numpy() for k, v in out.items()}, views))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, l0, o0, v0), (_, l1, o1, v1) = res
+    for f in l0:
+        if f == "dL_dmeans_2d":                       # per-view statistic: not reduced
+            assert np.array_equal(o0[f], l0[f]) and np.array_equal(o1[f], l1[f])
+        else:
+            assert np.allclose(o0[f], l0[f] + l1[f]) and np.array_equal(o0[f], o1[f])
+    assert set(v0).isdisjoint(v1) and v0 == [0, 2, 4, 6] and v1 == [1, 3, 5, 7]
+
+
+def test_allreduce_is_noop_without_process_group(pkg):
+    grads = pkg.BackwardOutput(*(torch.ones(2, k) for k in (3, 4, 3, 1)), torch.ones(2, 3, 1), torch.ones(2, 2))
+    assert pkg.parallel.allreduce_gradients(grads) == []
+    assert bool((grads.dL_dpositions == 1).all())

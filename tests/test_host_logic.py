@@ -1,0 +1,52 @@
+"""Host-side mirror of the reference's boundary types and the synthetic scene generator."""
+import numpy as np
+import torch
+
+
+def test_gaussian_model_validity_and_degree(pkg):
+    n = 5
+    m = pkg.GaussianModel(torch.zeros(n, 3), torch.zeros(n, 3, 16), torch.zeros(n, 1), torch.zeros(n, 4),
+                          torch.zeros(n, 3))
+    assert m.is_valid() and m.num_gaussians() == n and m.max_sh_degree() == 3
+    assert pkg.GaussianModel(torch.zeros(n, 3), torch.zeros(n, 3, 9), torch.zeros(n, 1), torch.zeros(n, 4),
+                             torch.zeros(n, 3)).max_sh_degree() == 2
+    assert not pkg.GaussianModel(torch.zeros(n, 3), torch.zeros(n, 3, 16), torch.zeros(n), torch.zeros(n, 4),
+                                 torch.zeros(n, 3)).is_valid()
+    assert not pkg.GaussianModel().is_valid()
+    assert pkg.sh_coeff_count(3) == 16
+
+
+def test_camera_to_abi(pkg):
+    cam = pkg.scene.make_camera(640, 480, view=2)
+    abi = cam.to_abi()
+    w2c = cam.world_to_camera()
+    assert np.allclose(np.array(list(abi.view), np.float32).reshape(4, 4), w2c)
+    R, t = cam.rotation.astype(np.float64), cam.translation.astype(np.float64)
+    assert np.allclose(np.array(list(abi.cam_center)), -R.T @ t, atol=1e-6)
+    assert (abi.width, abi.height) == (640, 480) and abi.fx == np.float32(0.78 * 640)
+    ident = pkg.scene.make_camera(64, 48)
+    assert np.array_equal(ident.rotation, np.eye(3, dtype=np.float32)) and not ident.translation.any()
+
+
+def test_scene_is_reproducible_and_shaped(pkg):
+    a = pkg.scene.make_gaussians(1000, 320, 240, sh_degree=3, seed=1234)
+    b = pkg.scene.make_gaussians(1000, 320, 240, sh_degree=3, seed=1234)
+    for k in a:
+        assert np.array_equal(a[k], b[k]) and a[k].dtype == np.float32
+    assert a["sh_coeffs"].shape == (1000, 3, 16) and a["opacities"].shape == (1000, 1)
+    assert np.allclose(np.linalg.norm(a["rotations"], axis=1), 1.0, atol=1e-6)
+    c = pkg.scene.make_gaussians(1000, 320, 240, sh_degree=3, seed=1235)
+    assert not np.array_equal(a["positions"], c["positions"])
+    g = pkg.scene.make_dl_dcolor(320, 240)
+    assert g.shape == (240, 320, 3) and abs(float(g.std()) * 320 * 240 - 1.0) < 0.05
+
+
+def test_render_rejects_cpu_model(pkg):
+    import pytest
+    n = 3
+    m = pkg.GaussianModel(torch.zeros(n, 3), torch.zeros(n, 3, 1), torch.zeros(n, 1), torch.zeros(n, 4),
+                          torch.zeros(n, 3))
+    with pytest.raises(RuntimeError, match="CUDA"):          # rasterizer.cpp:28
+        pkg.render(m, pkg.scene.make_camera(32, 32), pkg.RenderSettings())
+    with pytest.raises(RuntimeError, match="not valid"):     # rasterizer.cpp:27
+        pkg.render(pkg.GaussianModel(), pkg.scene.make_camera(32, 32), pkg.RenderSettings())

