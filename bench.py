@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py — forward+backward throughput of the MI355X-native Gaussian-splat rasterizer.
+
+    python bench.py --gpus N --steps K --warmup W [--config config3] [--adam]
+
+One "step" = one pass of the hot path over one training view per GPU:
+render() + render_backward() (+ the gradient all-reduce over RCCL when N > 1, + FusedAdam.step
+with --adam / config4).  Inputs (parameters, dL_dcolor) are resident in HBM before the timed
+region.  Default workload = BASELINE.json configs[2]: 1 M synthetic Gaussians, 1920x1080, SH
+degree 3 (scene generator: cuda-gaussian-splatting_amd/scene.py).
+
+Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
+  roofline      — the dominant kernel: ALGORITHMIC bytes per launch (SURVEY §8d per-unit figures x this
+                  run's N, P, pixels) / its mean duration from HIP events recorded on the launch stream
+                  inside the timed region; peak = 8.0 TB/s HBM3E (MI355X_MICROARCH.md);
+  frame_roofline— the same for the whole fwd+bwd frame (the north-star target is stated on it);
+  stages_ms     — mean per-stage durations from the same events;
+  cpu_baseline  — the CPU oracle (a port of the reference's CUDA kernels; the reference has no CPU path)
+                  timed on this box's host cores on a bounded sample of the same workload;
+  parity        — max-rel-err of RGB and gradients vs the oracle on a reduced scene (checker, not timed).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0      # same table: 6.29 TB/s measured float4 copy
+
+STAGES = ("project_forward", "sort", "raster_forward", "raster_backward", "project_backward")
+
+
+def algorithmic_bytes(n, c, p, w, h):
+    """SURVEY.md §8d, split by stage.  S = 8 + 24*ceil((32+ceil(log2 tiles))/8) is the survey's
+    sort term for the REFERENCE-shaped sort; kept as the algorithmic yardstick even though this
+    build's sort moves fewer bytes."""
+    tiles = ((w + 15) // 16) * ((h + 15) // 16)
+    s_sort = 8 + 24 * math.ceil((32 + math.ceil(math.log2(max(tiles, 2)))) / 8)
+    b = {
+        "project_forward": n * (44 + 12 * c + 48),
+        "sort": n * (8 + 20) + p * (12 + s_sort + 8) + tiles * 8,
+        "raster_forward": p * 40 + w * h * 20,
+        "raster_backward": n * 36 + p * (40 + 36) + w * h * 20,
+        "project_backward": n * (72 + 44 + 12 + 12 * c),
+    }
+    b["frame"] = sum(b.values())
+    b["adam"] = 28 * (11 + 3 * c) * n
+    return b
+
+
+def timed_step(pkg, model, cam, settings, g, events, ws, do_allreduce, opt):
+    """One step with a HIP event before/after every stage (events live on torch's current stream,
+    which is the stream every kernel of the C ABI is launched on)."""
+    R = pkg.rasterizer
+    n = model.num_gaussians()
+    deg = min(settings.active_sh_degree, model.max_sh_degree())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES) + 1)]
+    ev[0].record()
+    proj = R.project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs,
+                               cam, deg, settings.scale_modifier)
+    ev[1].record()
+    srt = R.sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, cam.width, cam.height,
+                           want_keys=False)
+    ev[2].record()
+    fwd = R.rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
+                              srt.gaussian_values_sorted, cam.width, cam.height, settings.background,
+                              packed=proj.packed)
+    ev[3].record()
+    rb = R.rasterize_backward(g, proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
+                              srt.gaussian_values_sorted, fwd.final_T, fwd.n_contrib, cam.width, cam.height,
+                              settings.background, n, packed=proj.packed, unpack=False)
+    ev[4].record()
+    d_means = torch.empty((n, 2), dtype=torch.float32, device=g.device)
+    pb = R.project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
+                            model.opacities, model.sh_coeffs, proj.radii, cam, deg, settings.scale_modifier,
+                            grad_accum=rb.grad_accum, rgb_clamped=proj.rgb, dL_dmeans_2d_out=d_means)
+    ev[5].record()
+    grads = pkg.BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
+                               pb.dL_dsh_coeffs, d_means)
+    if do_allreduce:
+        pkg.parallel.allreduce_gradients(grads)
+    if opt is not None:
+        opt.apply_gradients(grads)
+        opt.step()
+    events.append(ev)
+    return srt.total_pairs, fwd, grads
+
+
+def cpu_baseline(pkg, orc, wl, arrays, cam, g, budget_rows):
+    """The oracle on host cores, single thread, on a bounded sample of the SAME workload: the full
+    per-Gaussian work (projection, SH, pair sort) for all N Gaussians plus the blend forward+backward
+    of `budget_rows` image rows, extrapolated linearly in rows to the full frame."""
+    K = cam.intrinsics
+    t0 = time.perf_counter()
+    ref = orc.render(arrays, cam.rotation, cam.translation, K.fx, K.fy, K.cx, K.cy, wl.width, wl.height,
+                     active_degree=wl.sh_degree, rows=(0, 0))
+    t_n = time.perf_counter() - t0
+    budget_rows = min(budget_rows, wl.height)
+    r0 = (wl.height - budget_rows) // 2 // 16 * 16
+    rows = (r0, min(wl.height, r0 + budget_rows))
+    t0 = time.perf_counter()
+    fwd = orc.rasterize_forward(wl.width, wl.height, (0, 0, 0), ref["tile_ranges"], ref["values"], ref["means_2d"],
+                                ref["cov_2d_inv"], ref["rgb"], ref["opacities_act"], rows=rows)
+    orc.rasterize_backward(wl.width, wl.height, (0, 0, 0), ref["tile_ranges"], ref["values"], ref["means_2d"],
+                           ref["cov_2d_inv"], ref["rgb"], ref["opacities_act"], g, fwd["final_T"], fwd["n_contrib"],
+                           wl.n, rows=rows)
+    t_rows = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n = wl.n
+    gm, gc, go = np.zeros((n, 2), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    orc.project_backward(arrays["positions"], arrays["rotations"], arrays["scales"], arrays["opacities"],
+                         ref["view"], K.fx, K.fy, K.cx, K.cy, 1.0, ref["radii"], gm, gc, go)
+    orc.sh_backward(ref["degree"], arrays["sh_coeffs"], ref["dirs"], np.zeros((n, 3), np.float32))
+    t_nb = time.perf_counter() - t0
+    nrows = rows[1] - rows[0]
+    t_frame = t_n + t_nb + t_rows * wl.height / nrows
+    return {"value": wl.width * wl.height / t_frame / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": (f"oracle/cugs_oracle.c single-thread: projection+SH+sort+projection-bwd+SH-bwd of all "
+                       f"{wl.n} Gaussians ({t_n + t_nb:.2f} s) + blend fwd+bwd of image rows {rows[0]}..{rows[1]} "
+                       f"({t_rows:.2f} s), extrapolated x{wl.height / nrows:.2f} in rows to {wl.width}x{wl.height}"),
+            "seconds_measured": round(t_n + t_nb + t_rows, 3), "host_cores_available": os.cpu_count()}
+
+
+def parity_probe(pkg, orc, dev):
+    """Checker (not timed): reduced scene through the same code path vs the oracle."""
+    w, h, n = 640, 360, 20000
+    arrays = pkg.scene.make_gaussians(n, w, h, sh_degree=3, seed=77)
+    cam = pkg.scene.make_camera(w, h)
+    model = pkg.scene.to_model(arrays, dev)
+    st = pkg.RenderSettings()
+    out = pkg.render(model, cam, st)
+    g = pkg.scene.make_dl_dcolor(w, h)
+    grads = pkg.render_backward(torch.from_numpy(g).to(dev), out, model, cam, st)
+    K = cam.intrinsics
+    ref = orc.render(arrays, cam.rotation, cam.translation, K.fx, K.fy, K.cx, K.cy, w, h)
+    refb = orc.render_backward(g, ref, arrays, K.fx, K.fy, K.cx, K.cy, w, h)
+
+    def rel(a, b):
+        b64 = b.astype(np.float64).reshape(-1)
+        return float(np.max(np.abs(a.astype(np.float64).reshape(-1) - b64)) / max(np.max(np.abs(b64)), 1e-300))
+
+    res = {"scene": f"{n}/{w}x{h}/SH3 seed 77", "rgb": rel(out.color.cpu().numpy(), ref["color"]),
+           "sort_order_equal": bool(np.array_equal(out.gaussian_indices.cpu().numpy(), ref["values"])),
+           "n_contrib_equal": bool(np.array_equal(out.n_contrib.cpu().numpy(), ref["n_contrib"])),
+           "tiles_touched_equal": bool(np.array_equal(out.tile_ranges.cpu().numpy(), ref["tile_ranges"]))}
+    for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs"):
+        res[name] = rel(getattr(grads, name).cpu().numpy(), refb[name])
+    res["grad_max_rel_err"] = max(res[k] for k in res if k.startswith("dL_"))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="config3", choices=["config2", "config3", "config4"])
+    ap.add_argument("--adam", action="store_true", help="include FusedAdam.step in the step (implied by config4)")
+    ap.add_argument("--mu-s", type=float, default=None, help="override the log-scale mean (dense variant: -3.5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=1 << 20,
+                    help="image rows blended by the CPU baseline sample (default: the whole frame, ~10 s)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    n_gpus = world
+
+    ge._ensure_built()
+    pkg = ge.load_package()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    wl = pkg.scene.CONFIGS[args.config]
+    if args.mu_s is not None:
+        wl.mu_s = args.mu_s
+    forward_only = args.config == "config2"
+    use_adam = args.adam or args.config == "config4"
+    arrays = pkg.scene.make_gaussians(wl.n, wl.width, wl.height, sh_degree=wl.sh_degree, mu_s=wl.mu_s)
+    cam = pkg.scene.make_camera(wl.width, wl.height, view=rank)         # one distinct view per rank
+    model = pkg.scene.to_model(arrays, dev)
+    settings = pkg.RenderSettings(active_sh_degree=wl.sh_degree)
+    g_host = pkg.scene.make_dl_dcolor(wl.width, wl.height, seed=pkg.scene.GRAD_SEED + rank)
+    g = torch.from_numpy(g_host).to(dev)
+    opt = pkg.FusedAdam(model) if use_adam else None
+    c = pkg.sh_coeff_count(wl.sh_degree)
+
+    def step(events):
+        if forward_only:
+            out = pkg.render(model, cam, settings)
+            return out.total_pairs, out, None
+        return timed_step(pkg, model, cam, settings, g, events, None, world > 1, opt)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step([])
+    events = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pairs, _, _ = step(events)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_gpus * wl.width * wl.height * args.steps / elapsed / 1e6
+        alg = algorithmic_bytes(wl.n, c, pairs, wl.width, wl.height)
+        stages_ms = {}
+        if events:
+            for i, name in enumerate(STAGES):
+                stages_ms[name] = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for ev in events]))
+            gpu_ms = float(np.mean([ev[0].elapsed_time(ev[-1]) for ev in events]))
+            dom = max(stages_ms, key=stages_ms.get)
+            ach = alg[dom] / (stages_ms[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes": int(alg[dom]), "ms": round(stages_ms[dom], 4)}
+            fach = alg["frame"] / (gpu_ms * 1e-3) / 1e9
+            frame = {"algorithmic_bytes": int(alg["frame"]), "gpu_ms": round(gpu_ms, 4), "achieved": round(fach, 1),
+                     "unit": "GB/s", "frac_of_8TBs": round(fach / HBM_PEAK_GBS, 4),
+                     "frac_of_6.29TBs": round(fach / HBM_MEASURED_GBS, 4)}
+        else:
+            roofline = {"bound": "hbm", "kernel": "render(forward only)", "achieved": None, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": None, "traffic": None}
+            frame = None
+        out = {
+            "metric": "fwd+bwd Mpixels/s @1080p, 1M Gaussians, SH3" if args.config == "config3"
+                      else f"{'fwd' if forward_only else 'fwd+bwd' + ('+adam' if use_adam else '')} Mpixels/s, {wl.name}",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl.name + (" fwd only" if forward_only else " fwd+bwd") + (" +adam" if use_adam else ""),
+                       "n_gaussians": wl.n, "width": wl.width, "height": wl.height, "sh_degree": wl.sh_degree,
+                       "pairs": int(pairs), "mu_s": wl.mu_s, "views_per_step": n_gpus,
+                       "parallelism": f"dp{n_gpus}-views" + ("+rccl-allreduce" if n_gpus > 1 else "")},
+            "roofline": roofline, "frame_roofline": frame,
+            "stages_ms": {k: round(v, 4) for k, v in stages_ms.items()},
+        }
+        need_oracle = n_gpus == 1 and not (args.no_cpu_baseline and args.no_parity)
+        orc = ge.load_oracle() if need_oracle else None
+        if not args.no_cpu_baseline and n_gpus == 1:      # rank 0 at N=1 only
+            out["cpu_baseline"] = cpu_baseline(pkg, orc, wl, arrays, cam, g_host, args.cpu_rows)
+        if not args.no_parity and not forward_only and n_gpus == 1:
+            out["parity"] = parity_probe(pkg, orc, dev)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

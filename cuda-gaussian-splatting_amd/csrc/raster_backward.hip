@@ -206,8 +206,8 @@ extern "C" int cugs_rasterize_backward(int width, int height, const float backgr
     CUGS_RETURN_IF_HIP(hipMemsetAsync(grad_accum, 0, sizeof(float) * CUGS_GRAD_STRIDE * (size_t)n, st));
 
     const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
-    if (ntx > 0 && nty > 0) {                                   // backward.cu:267-269
-        if (!tile_ranges || !gaussian_indices || !dL_dcolor || !final_T || !n_contrib) return CUGS_EINVAL;
+    if (ntx > 0 && nty > 0 && gaussian_indices) {               // backward.cu:267-269; NULL indices = no pairs
+        if (!tile_ranges || !dL_dcolor || !final_T || !n_contrib) return CUGS_EINVAL;
         if (!packed && (!means_2d || !cov_2d_inv || !rgb || !opacities_act)) return CUGS_EINVAL;
         if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
         if ((int64_t)width * height > 2147483647ll / 3) return CUGS_EOVERFLOW;

@@ -104,11 +104,9 @@ extern "C" int cugs_rasterize_forward(int width, int height, const float backgro
     const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
     if (ntx == 0 || nty == 0) return 0;                       // forward.cu:204-210: nothing to draw
     if (!tile_ranges || !out_color || !out_final_T || !out_n_contrib) return CUGS_EINVAL;
-    if (!packed && (!means_2d || !cov_2d_inv || !rgb || !opacities_act)) {
-        // An empty scene has empty per-Gaussian arrays; the tile ranges are then all {0,0} and no
-        // record is ever read, so NULL sources are acceptable only together with NULL indices.
-        if (gaussian_indices) return CUGS_EINVAL;
-    }
+    // gaussian_indices and the per-Gaussian sources may be NULL for an empty pair list (P == 0: every
+    // tile range is {0,0} and nothing is dereferenced).  With indices present a source is required.
+    if (gaussian_indices && !packed && (!means_2d || !cov_2d_inv || !rgb || !opacities_act)) return CUGS_EINVAL;
     if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
     if ((int64_t)width * height > 2147483647ll / 3) return CUGS_EOVERFLOW;
     RasterGeom geo{width, height, ntx, ntx * nty, background_host[0], background_host[1], background_host[2]};

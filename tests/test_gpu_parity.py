@@ -87,8 +87,10 @@ def test_sort_equal_depth_ties_keep_index_order(pkg, orc, dev):
     vals = np_(srt.gaussian_values_sorted)
     assert np.array_equal(vals, ref["values"])
     tr = ref["tile_ranges"]
+    nzero = int((ref["keys"] == 0).sum())               # quirk Q12: leading (tile 0, Gaussian 0) pairs
+    assert nzero > 0 and not vals[:nzero].any()          # this scene has them: they must be reproduced
     for s, e in tr[tr[:, 1] > tr[:, 0]][:50]:
-        assert np.all(np.diff(vals[s:e]) > 0)
+        assert np.all(np.diff(vals[max(s, nzero):e]) > 0)
 
 
 def _forward_both(pkg, orc, dev, n, w, h, deg, mu_s, bg, seed=1234, view=0):
