@@ -111,19 +111,71 @@ __device__ __forceinline__ bool pixel_alpha(float pxf, float pyf, float mx, floa
     return !(r.alpha < (1.0f / 255.0f));
 }
 
-// Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic).  After the call
-// lanes 48..63 hold the total; other lanes hold partial sums.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
-    return v + __builtin_bit_cast(float, t);
+// ---------------------------------------------------------------------------------------
+// reduce9: sums NINE per-lane values across the 64 lanes of a wave and leaves each total in a
+// different lane (27 VALU-class operations instead of 9 x 6 DPP adds + a 9-way select).
+//
+// Idea ("transpose-reduce"): at every halving step two partner lanes exchange the half of the
+// values they will not keep, so the number of live values per lane halves as the number of lanes
+// sharing a sum doubles.  gfx950 has single instructions for the two cross-row exchanges:
+//   v_permlane32_swap D,S : swaps D[32..63] with S[0..31]         -> D+S = {sum32(D) | sum32(S)}
+//   v_permlane16_swap D,S : swaps D.row1<->S.row0, D.row3<->S.row2 -> D+S = rows {D, S, D, S}
+// and the in-row steps use DPP row_mirror / row_half_mirror / quad_perm with a select.
+// All 64 lanes must be active (EXEC full): callers run it in wave-uniform control flow with
+// zeros in lanes that have nothing to add.
+//
+// Result: after reduce9(v0..v8) the return value of lane L holds the wave total of slot
+// reduce9_slot(L) (or is meaningless when that is -1):
+//   row r = L >> 4, i = L & 15:  i == 0 -> {v0, v2, v1, v3}[r];  i == 8 -> {v4, v6, v5, v7}[r];
+//   i == 4 and r == 0 -> v8.
+// ---------------------------------------------------------------------------------------
+// The swaps are issued through inline asm: with ROCm 7.2's hipcc the two results of
+// __builtin_amdgcn_permlane{16,32}_swap collapse into one register when both feed the same add
+// (observed: `v_permlane32_swap v2, v3 ; v_add_f32 v2, v2, v2`).  hipcc pads nothing inside an asm
+// statement, so the 2 wait states it otherwise inserts between a VALU write and a swap that reads
+// the register (s_nop 1) are part of the string; each stage's swaps share one block.
+typedef unsigned cugs_u2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float wave_sum_to_row3(float v) {
-    v = dpp_add<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]   : + lane^1
-    v = dpp_add<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]   : + lane^2   (quad sums everywhere)
-    v = dpp_add<0x141, 0xF>(v);    // row_half_mirror       : 8-lane sums everywhere
-    v = dpp_add<0x140, 0xF>(v);    // row_mirror            : 16-lane row sums everywhere
-    v = dpp_add<0x142, 0xA>(v);    // row_bcast:15 -> rows 1,3: row1 = r0+r1, row3 = r2+r3
-    v = dpp_add<0x143, 0xC>(v);    // row_bcast:31 -> rows 2,3: row3 = r0+r1+r2+r3
-    return v;
+
+__device__ __forceinline__ int reduce9_slot(int lane) {
+    const int r = lane >> 4, i = lane & 15;
+    if (i == 0) return (r == 0) ? 0 : (r == 1) ? 2 : (r == 2) ? 1 : 3;
+    if (i == 8) return (r == 0) ? 4 : (r == 1) ? 6 : (r == 2) ? 5 : 7;
+    if (i == 4 && r == 0) return 8;
+    return -1;
+}
+
+__device__ __forceinline__ float reduce9(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                         float v7, float v8, int lane) {
+    // halves: lanes 0..31 keep the first of each pair, lanes 32..63 the second
+    float z8 = 0.0f;
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\t"
+                 "v_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\t"
+                 "v_permlane32_swap_b32 %6, %7\n\t"
+                 "v_permlane32_swap_b32 %8, %9"
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(z8));
+    float x0 = v0 + v1, x1 = v2 + v3, x2 = v4 + v5, x3 = v6 + v7, x4 = v8 + z8;
+    // rows: even rows keep the first, odd rows the second  -> rows {v0,v2,v1,v3}, {v4,v6,v5,v7}, {v8,0,0,0}
+    float z4 = 0.0f;
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\t"
+                 "v_permlane16_swap_b32 %2, %3\n\t"
+                 "v_permlane16_swap_b32 %4, %5"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(z4));
+    const float y0 = x0 + x1, y1 = x2 + x3, y2 = x4 + z4;
+    // in-row: i <-> 15-i ; lanes with bit3 = 0 keep y0, bit3 = 1 keep y1 ; y2 plain
+    const bool hi8 = (lane & 8) != 0;
+    const float z0 = (hi8 ? y1 : y0) + dpp_mov<0x140>(hi8 ? y0 : y1);
+    const float z1 = y2 + dpp_mov<0x140>(y2);
+    // i <-> i^7 ; bit2 = 0 keeps z0, bit2 = 1 keeps z1
+    const bool hi4 = (lane & 4) != 0;
+    float w = (hi4 ? z1 : z0) + dpp_mov<0x141>(hi4 ? z0 : z1);
+    w += dpp_mov<0x1B>(w);      // quad_perm [3,2,1,0]
+    w += dpp_mov<0xB1>(w);      // quad_perm [1,0,3,2]
+    return w;
 }

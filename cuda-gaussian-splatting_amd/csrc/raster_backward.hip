@@ -10,31 +10,34 @@
 //
 // What is different from the reference is the scatter.  The reference issues nine float atomics
 // per (pixel, Gaussian) contribution (backward.cu:217-228).  Here all 64 pixels of a wave look at
-// the same Gaussian in the same step, so the nine partials are summed across the wave with DPP row
-// operations, across the tile's four waves with ds_add_f32 into a per-batch LDS table, and leave
-// the workgroup once per (tile, Gaussian) as ONE atomic wave-instruction segment: 9 consecutive
-// floats of a 64-byte-aligned accumulator row (16 lanes per Gaussian, 4 Gaussians per instruction),
-// the shape that MI355X's memory-side float atomics serve at full rate (MI355X_MICROARCH.md §Global
-// float atomics).  Bytes added per frame: 36 B x P instead of 36 B x (contributions).
+// the same Gaussian in the same step, so the nine partials are first summed across the wave
+// (reduce9, cugs_raster_common.h: 27 operations, each total landing in a different lane) and then
+// leave the wave as ONE atomic wave-instruction whose nine active lanes hit nine consecutive floats
+// of the Gaussian's 64-byte-aligned accumulator row - a single memory-side request
+// (MI355X_MICROARCH.md, Global float atomics).  Measured (profiles/r01 ablation): the atomics are
+// free next to the evaluation; an earlier LDS stage that merged the four waves of a tile first cost
+// more in zero/flush/barrier overhead than it saved in requests.
 // The summation order differs from any sequential order; the oracle accumulates in fp64.
+// Per-contribution VALUES (not decisions) use v_rcp_f32 and fused multiply-adds: 1 ulp-level
+// differences from the oracle's divisions, far inside the 1e-4 bar.
 #include "cugs_raster_common.h"
+
+#include <stdlib.h>
 
 namespace {
 
-constexpr int ACC_STRIDE = 9;
-constexpr int ACC_LD = CUGS_BLOCK + 1;   // value k of Gaussian g at k*ACC_LD + g: banks (k+g)%32, conflict-free
 
 
-template <bool PACKED>
+// ABL: 0 = product; 1..3 = timing-only ablations selected by CUGS_BWD_ABLATE (tools/ablate_backward.py):
+// 1 no wave reduction, 2 no global atomics, 3 no per-pixel evaluation.  Outputs are wrong for ABL != 0.
+template <bool PACKED, int ABL>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, RasterSrc src,
                                                                 const float* __restrict__ dL_dcolor,
                                                                 const float* __restrict__ final_T,
                                                                 const int32_t* __restrict__ n_contrib,
                                                                 float* __restrict__ grad_accum) {
     __shared__ float4 s_rec[CUGS_BLOCK * CUGS_REC_F4];
-    __shared__ float s_acc[ACC_LD * ACC_STRIDE];
     __shared__ int s_gidx[CUGS_BLOCK];
-    __shared__ int s_touched[CUGS_BLOCK];
     __shared__ int s_wave_done[4];
 
     const unsigned tile = cugs_xcd_remap(blockIdx.x, (unsigned)geo.ntiles);
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     // (backward.cu:141-145), so it can start out finished.
     bool done = !inside || max_contrib <= 0;
     bool wave_done = (__ballot(!done) == 0ull);
+    const int my_slot = reduce9_slot(lane);
 
     for (int batch = num_batches - 1; batch >= 0; --batch) {
         if (lane == 0) s_wave_done[wave] = wave_done ? 1 : 0;
@@ -73,9 +77,6 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         if (s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) break;
 
         s_gidx[tid] = stage_record<PACKED>(src, range_start + batch * CUGS_BLOCK + tid, range_end, s_rec);
-        s_touched[tid] = 0;
-#pragma unroll
-        for (int k = 0; k < ACC_STRIDE; ++k) s_acc[k * ACC_LD + tid] = 0.0f;
         __syncthreads();
 
         if (!wave_done) {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                     float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f, v5 = 0.0f, v6 = 0.0f,
                           v7 = 0.0f, v8 = 0.0f;
                     bool contrib = false;
-                    if (!done) {
+                    if (ABL != 3 && !done) {
                         PixelEval e;
                         if (pixel_alpha(pxf, pyf, g0.x, g0.y, a, b, c, o, e)) {
                             ++found;
@@ -109,62 +110,47 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                             } else {
                                 contrib = true;
                                 const float oma = fmaxf(1.0f - e.alpha, 1e-5f);
-                                T /= oma;
+                                const float rcp = __builtin_amdgcn_rcpf(oma);
+                                T *= rcp;                                   // T_before = T_after / (1 - alpha)
                                 const float weight = e.alpha * T;
                                 v0 = dC0 * weight;
                                 v1 = dC1 * weight;
                                 v2 = dC2 * weight;
-                                float dL_dalpha = 0.0f;
-                                dL_dalpha += dC0 * (T * g1.y - S0 / oma);
-                                dL_dalpha += dC1 * (T * g1.z - S1 / oma);
-                                dL_dalpha += dC2 * (T * g1.w - S2 / oma);
-                                S0 += weight * g1.y;
-                                S1 += weight * g1.z;
-                                S2 += weight * g1.w;
-                                float dL_dopa = dL_dalpha * e.e;
-                                float dL_dpower = dL_dalpha * e.alpha;
-                                if (o * e.e >= 0.99f) { dL_dopa = 0.0f; dL_dpower = 0.0f; }
-                                v3 = dL_dopa;
-                                v4 = dL_dpower * (a * e.dx + b * e.dy);
-                                v5 = dL_dpower * (b * e.dx + c * e.dy);
-                                v6 = dL_dpower * (-0.5f * e.dx * e.dx);
-                                v7 = dL_dpower * (-e.dx * e.dy);
-                                v8 = dL_dpower * (-0.5f * e.dy * e.dy);
+                                float dL_dalpha = dC0 * fmaf(T, g1.y, -S0 * rcp);
+                                dL_dalpha = fmaf(dC1, fmaf(T, g1.z, -S1 * rcp), dL_dalpha);
+                                dL_dalpha = fmaf(dC2, fmaf(T, g1.w, -S2 * rcp), dL_dalpha);
+                                S0 = fmaf(weight, g1.y, S0);
+                                S1 = fmaf(weight, g1.z, S1);
+                                S2 = fmaf(weight, g1.w, S2);
+                                const bool clamped = (o * e.e >= 0.99f);
+                                v3 = clamped ? 0.0f : dL_dalpha * e.e;
+                                const float dL_dpower = clamped ? 0.0f : dL_dalpha * e.alpha;
+                                v4 = dL_dpower * fmaf(a, e.dx, b * e.dy);
+                                v5 = dL_dpower * fmaf(b, e.dx, c * e.dy);
+                                const float hdp = -0.5f * dL_dpower;
+                                v6 = hdp * e.dx * e.dx;
+                                v7 = -dL_dpower * e.dx * e.dy;
+                                v8 = hdp * e.dy * e.dy;
                             }
                         }
                     }
                     // wave-uniform from here: all 64 lanes take part in the DPP sums
-                    if (__ballot(contrib) != 0ull) {
-                        v0 = wave_sum_to_row3(v0); v1 = wave_sum_to_row3(v1); v2 = wave_sum_to_row3(v2);
-                        v3 = wave_sum_to_row3(v3); v4 = wave_sum_to_row3(v4); v5 = wave_sum_to_row3(v5);
-                        v6 = wave_sum_to_row3(v6); v7 = wave_sum_to_row3(v7); v8 = wave_sum_to_row3(v8);
-                        const int k = lane - 48;                          // lanes 48..56 carry value k
-                        if (k >= 0 && k < ACC_STRIDE) {
-                            float mine = v0;
-                            mine = (k == 1) ? v1 : mine; mine = (k == 2) ? v2 : mine;
-                            mine = (k == 3) ? v3 : mine; mine = (k == 4) ? v4 : mine;
-                            mine = (k == 5) ? v5 : mine; mine = (k == 6) ? v6 : mine;
-                            mine = (k == 7) ? v7 : mine; mine = (k == 8) ? v8 : mine;
-                            atomicAdd(&s_acc[k * ACC_LD + jj], mine);  // ds_add_f32, other waves too
-                            if (k == 0) s_touched[jj] = 1;
+                    if (ABL == 1) {
+                        asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8));
+                    } else if (__ballot(contrib) != 0ull) {
+                        // wave-uniform: all 64 lanes take part in the exchange
+                        const float total = reduce9(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
+                        if (ABL == 2) {
+                            asm volatile("" ::"v"(total));
+                        } else if (my_slot >= 0) {
+                            atomicAdd(&grad_accum[(int64_t)s_gidx[jj] * CUGS_GRAD_STRIDE + my_slot], total);
                         }
                     }
                     if (__ballot(!done) == 0ull) { wave_done = true; break; }
                 }
             }
         }
-        __syncthreads();
-
-        // One 64-byte accumulator row per touched Gaussian: 16 lanes per row, 9 of them adding.
-        {
-            const int batch_count = min(CUGS_BLOCK, num_in_range - batch * CUGS_BLOCK);
-            for (int e = tid; e < batch_count * 16; e += CUGS_BLOCK) {
-                const int g = e >> 4, k = e & 15;
-                if (k < ACC_STRIDE && s_touched[g])
-                    atomicAdd(&grad_accum[(int64_t)s_gidx[g] * CUGS_GRAD_STRIDE + k], s_acc[k * ACC_LD + g]);
-            }
-        }
-        // the next iteration's first barrier orders these LDS reads before the re-zeroing
+        // the next iteration's first barrier orders this batch's LDS reads before the re-staging
     }
 }
 
@@ -213,12 +199,20 @@ extern "C" int cugs_rasterize_backward(int width, int height, const float backgr
         if ((int64_t)width * height > 2147483647ll / 3) return CUGS_EOVERFLOW;
         RasterGeom geo{width, height, ntx, ntx * nty, background_host[0], background_host[1], background_host[2]};
         RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act};
-        if (packed)
-            hipLaunchKernelGGL((k_raster_backward<true>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src,
-                               dL_dcolor, final_T, n_contrib, grad_accum);
-        else
-            hipLaunchKernelGGL((k_raster_backward<false>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src,
-                               dL_dcolor, final_T, n_contrib, grad_accum);
+        const char* abl_env = getenv("CUGS_BWD_ABLATE");          // timing experiments only
+        const int abl = abl_env ? atoi(abl_env) : 0;
+#define CUGS_LAUNCH_BWD(P, A)                                                                              \
+    hipLaunchKernelGGL((k_raster_backward<P, A>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src, \
+                       dL_dcolor, final_T, n_contrib, grad_accum)
+        if (packed) {
+            if (abl == 1) CUGS_LAUNCH_BWD(true, 1);
+            else if (abl == 2) CUGS_LAUNCH_BWD(true, 2);
+            else if (abl == 3) CUGS_LAUNCH_BWD(true, 3);
+            else CUGS_LAUNCH_BWD(true, 0);
+        } else {
+            CUGS_LAUNCH_BWD(false, 0);
+        }
+#undef CUGS_LAUNCH_BWD
         CUGS_LAUNCH_CHECK();
     }
     if (n_soa == 4) {
@@ -226,5 +220,21 @@ extern "C" int cugs_rasterize_backward(int width, int height, const float backgr
                            0, st, n, grad_accum, dL_drgb, dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv);
         CUGS_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// ---- test hook (not part of include/cugs_hip.h): one wave runs reduce9 on caller data ----------
+// in: [9][64] floats (value k of lane l at k*64+l); out: [64] floats (each lane's result), slots: [64] ints.
+namespace {
+__global__ void k_dbg_reduce9(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ slots) {
+    const int l = threadIdx.x;
+    out[l] = reduce9(in[0 * 64 + l], in[1 * 64 + l], in[2 * 64 + l], in[3 * 64 + l], in[4 * 64 + l], in[5 * 64 + l],
+                     in[6 * 64 + l], in[7 * 64 + l], in[8 * 64 + l], l);
+    slots[l] = reduce9_slot(l);
+}
+}  // namespace
+extern "C" int cugsdbg_reduce9(const float* in, float* out, int* slots, void* stream) {
+    hipLaunchKernelGGL(k_dbg_reduce9, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in, out, slots);
+    CUGS_LAUNCH_CHECK();
     return 0;
 }

@@ -393,7 +393,7 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const int32_t* tiles_touched, vo
     unsigned long long* total = static_cast<unsigned long long*>(workspace);
     CUGS_RETURN_IF_HIP(hipMemsetAsync(total, 0, sizeof(unsigned long long), st));
     const int64_t want = (n + CUGS_BLOCK - 1) / CUGS_BLOCK;
-    const int grid = (int)(want < 2048 ? want : 2048);
+    const int grid = (int)(want < 256 ? want : 256);   // one u64 atomic per workgroup on a single word
     hipLaunchKernelGGL(k_sum_tiles, dim3(grid), dim3(CUGS_BLOCK), 0, st, n, tiles_touched, total);
     CUGS_LAUNCH_CHECK();
     unsigned long long host_total = 0;

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Dev tool: A/B timing of k_raster_backward ablations in ONE process (cdna_hip_programming.md rule 24).
+Usage (on the GPU box): python tools/ablate_backward.py [--mu-s -4.6]"""
+import argparse, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+
+ap = argparse.ArgumentParser(); ap.add_argument("--mu-s", type=float, default=-4.6); ap.add_argument("--rounds", type=int, default=8)
+ap.add_argument("--variants", default="0,1,2,3")
+a = ap.parse_args()
+pkg = ge.load_package(); dev = torch.device("cuda:0")
+wl = pkg.scene.CONFIGS["config3"]
+arr = pkg.scene.make_gaussians(wl.n, wl.width, wl.height, 3, mu_s=a.mu_s); cam = pkg.scene.make_camera(wl.width, wl.height)
+model = pkg.scene.to_model(arr, dev); st = pkg.RenderSettings()
+out = pkg.render(model, cam, st); g = torch.from_numpy(pkg.scene.make_dl_dcolor(wl.width, wl.height)).to(dev)
+nc = out.n_contrib.float()
+print("pairs", out.total_pairs, "n_contrib mean %.1f max %d  saturated %.3f" % (nc.mean().item(), int(nc.max().item()), (out.final_T < 1/255).float().mean().item()))
+R = pkg.rasterizer
+def run():
+    return R.rasterize_backward(g, out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges, out.gaussian_indices,
+                                out.final_T, out.n_contrib, wl.width, wl.height, st.background, wl.n, packed=out.packed, unpack=False)
+variants = [int(v) for v in a.variants.split(",")]
+times = {v: [] for v in variants}
+for r in range(a.rounds):
+    for v in variants:
+        os.environ["CUGS_BWD_ABLATE"] = str(v)
+        run(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
+        times[v].append(e0.elapsed_time(e1))
+os.environ.pop("CUGS_BWD_ABLATE", None)
+for v in variants:
+    print("ABL", v, "median %.3f ms  min %.3f" % (float(np.median(times[v])), min(times[v])))
+# forward for reference
+ts = []
+for r in range(a.rounds):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); R.rasterize_forward(out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges, out.gaussian_indices, wl.width, wl.height, st.background, packed=out.packed); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+print("forward median %.3f ms" % float(np.median(ts)))
