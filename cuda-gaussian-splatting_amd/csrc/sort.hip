@@ -21,8 +21,7 @@ constexpr int RADIX = 256;
 constexpr int IPT = 16;                           // items per thread
 constexpr int CHUNK = CUGS_BLOCK * IPT;           // 4096 items per workgroup
 constexpr int WAVE_ITEMS = CUGS_WAVE * IPT;       // 1024 contiguous items per wave
-constexpr int FILL_IPT = 4;
-constexpr int FILL_CHUNK = CUGS_BLOCK * FILL_IPT; // Gaussians per workgroup in scan/fill
+constexpr int FILL_CHUNK = CUGS_BLOCK;            // Gaussians per workgroup in scan/fill (one per thread)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline uint32_t nblocks_for(int64_t count, int chunk) { return (uint32_t)((count + chunk - 1) / chunk); }
@@ -180,18 +179,30 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(uint32_t* __rest
     if (threadIdx.x == 0) tot[blockIdx.x] = carry;
 }
 
+// Stable scatter.  Ranking: each wave owns a contiguous 1024-item slice and walks it in rounds of
+// 64; in a round the lanes holding the same digit find each other with 8 ballots (match-any), the
+// rank is the popcount below the lane, and the group's highest lane advances the wave's running
+// base in LDS.  The (key, value) pairs are first placed at their position in the workgroup's LOCALLY
+// sorted order in LDS and then streamed out, so that consecutive lanes write consecutive global
+// addresses inside each digit's run (4 B items scattered straight to 128-256 buckets cost ~2x).
 template <bool SRC_DEPTH>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count,
     int shift, uint32_t mask, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ tot,
     uint32_t nblk, uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-    __shared__ uint32_t s_wave_base[4][RADIX];
+    __shared__ uint32_t s_lbase[4][RADIX];     // per (wave, digit): count, then running LOCAL position
+    __shared__ uint32_t s_lstart[RADIX];       // first local position of digit d
+    __shared__ uint32_t s_gbase[RADIX];        // first global position of this workgroup's digit-d run
+    __shared__ uint32_t s_key[CHUNK];
+    __shared__ uint32_t s_val[CHUNK];
     __shared__ uint32_t s_tmp[4];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t wbase = blockIdx.x * CHUNK + wave * WAVE_ITEMS;
+    const uint32_t bbase = blockIdx.x * CHUNK;
+    const uint32_t wbase = bbase + wave * WAVE_ITEMS;
+    const uint32_t count_blk = min((uint32_t)CHUNK, count - bbase);
 
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s_wave_base[w][tid] = 0;
+    for (int w = 0; w < 4; ++w) s_lbase[w][tid] = 0;
     __syncthreads();
 
     uint32_t k[IPT], v[IPT];
@@ -199,23 +210,22 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scatter(
     for (int r = 0; r < IPT; ++r) {
         uint32_t i = wbase + r * CUGS_WAVE + lane;
         bool ok = i < count;
-        k[r] = ok ? load_key<SRC_DEPTH>(keys_in, i) : 0xFFFFFFFFu;
+        k[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
         v[r] = ok ? (SRC_DEPTH ? i : vals_in[i]) : 0u;
-        if (ok) atomicAdd(&s_wave_base[wave][(k[r] >> shift) & mask], 1u);
+        if (ok) atomicAdd(&s_lbase[wave][(k[r] >> shift) & mask], 1u);
     }
     __syncthreads();
 
-    // digit d (= tid): global base + this workgroup's offset, then split across the 4 waves
-    {
-        uint32_t dig_total = tot[tid];
-        uint32_t dig_base = block_exclusive_scan(dig_total, s_tmp, nullptr);
-        uint32_t b = dig_base + hist[tid * nblk + blockIdx.x];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            uint32_t c = s_wave_base[w][tid];
-            s_wave_base[w][tid] = b;
-            b += c;
-        }
+    {   // digit d = tid
+        const uint32_t c0 = s_lbase[0][tid], c1 = s_lbase[1][tid], c2 = s_lbase[2][tid], c3 = s_lbase[3][tid];
+        const uint32_t dig_base = block_exclusive_scan(tot[tid], s_tmp, nullptr);            // global digit start
+        const uint32_t lstart = block_exclusive_scan(c0 + c1 + c2 + c3, s_tmp, nullptr);     // local digit start
+        s_gbase[tid] = dig_base + hist[tid * nblk + blockIdx.x];
+        s_lstart[tid] = lstart;
+        s_lbase[0][tid] = lstart;
+        s_lbase[1][tid] = lstart + c0;
+        s_lbase[2][tid] = lstart + c0 + c1;
+        s_lbase[3][tid] = lstart + c0 + c1 + c2;
     }
     __syncthreads();
 
@@ -225,7 +235,6 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scatter(
         const uint32_t i = wbase + r * CUGS_WAVE + lane;
         const bool ok = i < count;
         const uint32_t d = (k[r] >> shift) & mask;
-        // lanes of this wave holding the same digit (wave64 match-any via 8 ballots)
         unsigned long long peers = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -234,13 +243,24 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scatter(
             peers &= bit ? m : ~m;
         }
         if (ok) {
-            const uint32_t rank = __popcll(peers & lt_mask);
-            const uint32_t base = s_wave_base[wave][d];
-            const uint32_t dst = base + rank;
-            keys_out[dst] = k[r];
-            vals_out[dst] = v[r];
-            if ((peers >> lane) == 1ull)           // highest lane of the group advances the base
-                s_wave_base[wave][d] = base + __popcll(peers);
+            const uint32_t base = s_lbase[wave][d];
+            const uint32_t pos = base + __popcll(peers & lt_mask);
+            s_key[pos] = k[r];
+            s_val[pos] = v[r];
+            if ((peers >> lane) == 1ull) s_lbase[wave][d] = base + __popcll(peers);
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const uint32_t j = r * CUGS_BLOCK + tid;
+        if (j < count_blk) {
+            const uint32_t key = s_key[j];
+            const uint32_t d = (key >> shift) & mask;
+            const uint32_t dst = s_gbase[d] + (j - s_lstart[d]);
+            keys_out[dst] = key;
+            vals_out[dst] = s_val[j];
         }
     }
 }
@@ -253,12 +273,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_blocksums(uint32_t n,
                                                                const int32_t* __restrict__ tiles,
                                                                uint32_t* __restrict__ blocksum) {
     __shared__ uint32_t s_tmp[4];
-    uint32_t acc = 0;
-#pragma unroll
-    for (int j = 0; j < FILL_IPT; ++j) {
-        uint32_t i = blockIdx.x * FILL_CHUNK + threadIdx.x * FILL_IPT + j;
-        if (i < n) acc += (uint32_t)tiles[order[i]];
-    }
+    const uint32_t i = blockIdx.x * FILL_CHUNK + threadIdx.x;
+    const uint32_t acc = i < n ? (uint32_t)tiles[order[i]] : 0u;
     uint32_t total;
     block_exclusive_scan(acc, s_tmp, &total);
     if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
@@ -280,7 +296,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_scan_blocksums(uint32_t* __restr
 }
 
 // k_fill_sort_pairs (sorting.cu:30-72), walked in depth order; only the tile id and the index are
-// stored (the depth half of the key is implied by the order).
+// stored (the depth half of the key is implied by the order).  One Gaussian per thread computes
+// its rectangle and its offset (workgroup scan); the workgroup then emits its pairs COOPERATIVELY:
+// output position k is owned by lane k % 256, which finds the Gaussian by binary search over the
+// 256 offsets in LDS - consecutive lanes write consecutive pairs (fully coalesced), and a splat
+// covering thousands of tiles no longer serialises one thread.
 __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     uint32_t n, uint32_t total_pairs, const uint32_t* __restrict__ order,
     const int32_t* __restrict__ tiles, const float* __restrict__ means_2d,
@@ -288,40 +308,58 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     const uint32_t* __restrict__ blocksum, uint32_t* __restrict__ ptile, uint32_t* __restrict__ pidx,
     uint32_t* __restrict__ zero_pairs) {
     __shared__ uint32_t s_tmp[4];
-    uint32_t g[FILL_IPT], t[FILL_IPT], acc = 0;
-#pragma unroll
-    for (int j = 0; j < FILL_IPT; ++j) {
-        uint32_t i = blockIdx.x * FILL_CHUNK + threadIdx.x * FILL_IPT + j;
-        g[j] = i < n ? order[i] : 0u;
-        t[j] = i < n ? (uint32_t)tiles[g[j]] : 0u;
-        acc += t[j];
-    }
-    uint32_t pos = blocksum[blockIdx.x] + block_exclusive_scan(acc, s_tmp, nullptr);
-#pragma unroll
-    for (int j = 0; j < FILL_IPT; ++j) {
-        if (t[j] == 0) continue;
-        const uint32_t idx = g[j];
-        uint32_t w = pos;
-        const uint32_t end = min(pos + t[j], total_pairs);         // never write past the buffers
-        const int radius = radii[idx];
-        if (radius > 0) {                                           // sorting.cu:44-45
-            const TileRect tr = tile_rect_of(means_2d[idx * 2 + 0], means_2d[idx * 2 + 1], radius, img_w,
-                                             img_h, ntx, nty);
-            for (int ty = tr.y0; ty < tr.y1; ++ty)
-                for (int tx = tr.x0; tx < tr.x1; ++tx) {
-                    if (w < end) {
-                        ptile[w] = (uint32_t)(ty * ntx + tx);
-                        pidx[w] = idx;
-                    }
-                    ++w;
+    __shared__ uint32_t s_off[CUGS_BLOCK + 1];
+    __shared__ uint32_t s_g[CUGS_BLOCK];
+    __shared__ int s_x0[CUGS_BLOCK], s_y0[CUGS_BLOCK], s_w[CUGS_BLOCK], s_cnt[CUGS_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * FILL_CHUNK + tid;
+    uint32_t g = 0, t = 0;
+    int x0 = 0, y0 = 0, w = 0, real = 0;          // real = pairs the reference's loops would write
+    if (i < n) {
+        g = order[i];
+        t = (uint32_t)tiles[g];
+        if (t > 0) {
+            const int radius = radii[g];
+            if (radius > 0) {                                        // sorting.cu:44-45
+                const TileRect tr = tile_rect_of(means_2d[g * 2 + 0], means_2d[g * 2 + 1], radius, img_w, img_h,
+                                                 ntx, nty);
+                if (tr.x1 > tr.x0 && tr.y1 > tr.y0) {
+                    x0 = tr.x0; y0 = tr.y0; w = tr.x1 - tr.x0;
+                    real = w * (tr.y1 - tr.y0);
                 }
+            }
+            if ((uint32_t)real < t) atomicAdd(zero_pairs, t - (uint32_t)real);   // quirk Q12 slots (rare)
         }
-        if (w < end) atomicAdd(zero_pairs, end - w);               // rare
-        for (; w < end; ++w) {                                      // slots the reference leaves at zero (Q12)
-            ptile[w] = 0u;
-            pidx[w] = 0u;
+    }
+    uint32_t blk_total;
+    const uint32_t off = block_exclusive_scan(t, s_tmp, &blk_total);
+    s_off[tid] = off;
+    s_g[tid] = g; s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = w; s_cnt[tid] = real;
+    if (tid == 0) s_off[CUGS_BLOCK] = blk_total;
+    __syncthreads();
+
+    const uint32_t out_base = blocksum[blockIdx.x];
+    for (uint32_t k = tid; k < blk_total; k += CUGS_BLOCK) {
+        // largest j with s_off[j] <= k among entries with a non-empty span: upper_bound - 1
+        uint32_t lo = 0, hi = CUGS_BLOCK;                            // invariant: s_off[lo] <= k < s_off[hi]
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_off[mid] <= k) lo = mid; else hi = mid;
         }
-        pos += t[j];
+        const uint32_t local = k - s_off[lo];
+        uint32_t tile = 0u, idx = 0u;                                // slots the reference leaves at zero (Q12)
+        if ((int)local < s_cnt[lo]) {
+            const int ww = s_w[lo];
+            const int row = (int)local / ww;
+            tile = (uint32_t)((s_y0[lo] + row) * ntx + s_x0[lo] + ((int)local - row * ww));
+            idx = s_g[lo];
+        }
+        const uint32_t dst = out_base + k;
+        if (dst < total_pairs) {                                     // never write past the buffers
+            ptile[dst] = tile;
+            pidx[dst] = idx;
+        }
     }
 }
 
