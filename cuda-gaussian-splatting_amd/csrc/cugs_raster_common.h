@@ -34,7 +34,9 @@ struct RasterSrc {
     const float* opa;
 };
 
-// Stage list entry `li` (if < end) into LDS slot threadIdx.x.  Returns the Gaussian index (or -1).
+// Stage list entry `li` (if < end) into LDS slot threadIdx.x.  The LDS copy of the record carries the
+// Gaussian index (as bits) in word 10 in place of 1/a, so that the backward's scatter address comes
+// with the same 16-byte read as the opacity.  Returns the Gaussian index (or -1).
 template <bool PACKED>
 __device__ __forceinline__ int stage_record(const RasterSrc& s, int li, int end, float4* s_rec) {
     if (li >= end) return -1;
@@ -47,17 +49,18 @@ __device__ __forceinline__ int stage_record(const RasterSrc& s, int li, int end,
         const float a = s.cov_2d_inv[g * 3 + 0], c = s.cov_2d_inv[g * 3 + 2], o = s.opa[g];
         r0 = make_float4(s.means_2d[g * 2 + 0], s.means_2d[g * 2 + 1], a, s.cov_2d_inv[g * 3 + 1]);
         r1 = make_float4(c, s.rgb[g * 3 + 0], s.rgb[g * 3 + 1], s.rgb[g * 3 + 2]);
-        r2 = make_float4(o, (o >= (1.0f / 255.0f)) ? logf(255.0f * o) : -1.0f,
-                         a > 0.0f ? 1.0f / a : 0.0f, c > 0.0f ? 1.0f / c : 0.0f);
+        r2 = make_float4(o, (o >= (1.0f / 255.0f)) ? logf(255.0f * o) : -1.0f, 0.0f, 0.0f);
     }
+    r2.z = __int_as_float(g);
     s_rec[threadIdx.x * CUGS_REC_F4 + 0] = r0;
     s_rec[threadIdx.x * CUGS_REC_F4 + 1] = r1;
     s_rec[threadIdx.x * CUGS_REC_F4 + 2] = r2;
     return g;
 }
 
-// Can the Gaussian in (r0, r1, r2) reach alpha >= 1/255 at ANY pixel centre of the 8x8 quad whose
-// first centre is (qx0, qy0)?  `false` only when certainly not.
+// Can the Gaussian in (r0, r1, r2) reach alpha >= 1/255 at ANY pixel centre of the rectangle of
+// centres [qx0, qx0+wx] x [qy0, qy0+wy] (the wave's quad, or the bounding box of its pixels that are
+// still active: ActiveRect below)?  `false` only when certainly not.
 //
 // alpha = min(0.99, o * exp(power)) >= 1/255 needs -power <= tau := ln(255 o)  (tau < 0: never;
 // the record stores tau = -1 for o < 1/255, where o * exp(power <= 0) <= o < 1/255 exactly).
@@ -68,12 +71,14 @@ __device__ __forceinline__ int stage_record(const RasterSrc& s, int li, int end,
 // B = |a| X^2 + 2 |b| X Y + |c| Y^2 (X, Y the largest |offset|); q_min here carries a similar
 // error; ocml logf ~2 ulp; detexp 1 ulp.  The slack 0.01 tau + 0.05 + 4e-6 B dominates all of it
 // by orders of magnitude.  Any NaN makes the final comparison false -> not culled.
-__device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float4 r2, float qx0, float qy0) {
+__device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float4 r2, float qx0, float qy0,
+                                               float wx, float wy) {
     const float mx = r0.x, my = r0.y, a = r0.z, b = r0.w, c = r1.x;
-    const float tau = r2.y, ia = r2.z, ic = r2.w;
+    const float tau = r2.y;
     if (!(tau >= 0.0f)) return false;
     if (!(a > 0.0f && c > 0.0f)) return true;
-    const float lx = qx0 - mx, hx = lx + 7.0f, ly = qy0 - my, hy = ly + 7.0f;
+    const float ia = __builtin_amdgcn_rcpf(a), ic = __builtin_amdgcn_rcpf(c);   // cull only: 1 ulp is irrelevant
+    const float lx = qx0 - mx, hx = lx + wx, ly = qy0 - my, hy = ly + wy;
     const bool inside = (lx <= 0.0f) && (hx >= 0.0f) && (ly <= 0.0f) && (hy >= 0.0f);
     const float X = fmaxf(fabsf(lx), fabsf(hx)), Y = fmaxf(fabsf(ly), fabsf(hy));
     const float B = a * X * X + 2.0f * fabsf(b) * X * Y + c * Y * Y;
@@ -89,6 +94,21 @@ __device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float4 r2, 
     const float q4 = a * x4 * x4 + b2 * x4 * hy + c * hy * hy;
     const float qmin = inside ? 0.0f : fminf(fminf(q1, q2), fminf(q3, q4));
     return !(0.5f * qmin > tau * 1.01f + 0.05f + 4e-6f * B);
+}
+
+// Bounding box, in quad coordinates 0..7, of the lanes set in `active` (lane = y*8 + x; active != 0).
+// Pure scalar bit arithmetic on the wave-uniform ballot.  Pixels that are finished (or outside the
+// image) can no longer be affected by any Gaussian, so culling against the box of the remaining
+// ones stays conservative and prunes the tail where only a few pixels of a quad are still open.
+struct ActiveRect { float x0, y0, wx, wy; };
+__device__ __forceinline__ ActiveRect active_rect(unsigned long long active, float quad_cx, float quad_cy) {
+    unsigned cols = (unsigned)active | (unsigned)(active >> 32);
+    cols |= cols >> 16;
+    cols |= cols >> 8;
+    cols &= 0xFFu;
+    const int x0 = __builtin_ctz(cols), x1 = 31 - __builtin_clz(cols);
+    const int y0 = __builtin_ctzll(active) >> 3, y1 = (63 - __builtin_clzll(active)) >> 3;
+    return ActiveRect{quad_cx + (float)x0, quad_cy + (float)y0, (float)(x1 - x0), (float)(y1 - y0)};
 }
 
 // forward.cu:124-141 / backward.cu:123-137 for one pixel.  FMA placement contract:

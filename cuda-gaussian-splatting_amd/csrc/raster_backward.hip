@@ -29,15 +29,15 @@ namespace {
 
 
 // ABL: 0 = product; 1..3 = timing-only ablations selected by CUGS_BWD_ABLATE (tools/ablate_backward.py):
-// 1 no wave reduction, 2 no global atomics, 3 no per-pixel evaluation.  Outputs are wrong for ABL != 0.
+// 1 no wave reduction, 2 no global atomics, 3 no per-pixel evaluation, 4 = product + step counters written to
+// accumulator row n (the tool allocates n+1 rows).  Outputs are wrong for ABL 1..3.
 template <bool PACKED, int ABL>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, RasterSrc src,
                                                                 const float* __restrict__ dL_dcolor,
                                                                 const float* __restrict__ final_T,
                                                                 const int32_t* __restrict__ n_contrib,
-                                                                float* __restrict__ grad_accum) {
+                                                                float* __restrict__ grad_accum, int64_t stats_row) {
     __shared__ float4 s_rec[CUGS_BLOCK * CUGS_REC_F4];
-    __shared__ int s_gidx[CUGS_BLOCK];
     __shared__ int s_wave_done[4];
 
     const unsigned tile = cugs_xcd_remap(blockIdx.x, (unsigned)geo.ntiles);
@@ -70,87 +70,104 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     bool done = !inside || max_contrib <= 0;
     bool wave_done = (__ballot(!done) == 0ull);
     const int my_slot = reduce9_slot(lane);
+    unsigned st_steps = 0, st_contrib = 0, st_lanes = 0, st_batches = 0, st_tested = 0;   // ABL == 4 only
 
     for (int batch = num_batches - 1; batch >= 0; --batch) {
         if (lane == 0) s_wave_done[wave] = wave_done ? 1 : 0;
         __syncthreads();
         if (s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) break;
 
-        s_gidx[tid] = stage_record<PACKED>(src, range_start + batch * CUGS_BLOCK + tid, range_end, s_rec);
+        stage_record<PACKED>(src, range_start + batch * CUGS_BLOCK + tid, range_end, s_rec);
         __syncthreads();
 
+        if (ABL == 4 && !wave_done) ++st_batches;
         if (!wave_done) {
             const int batch_count = min(CUGS_BLOCK, num_in_range - batch * CUGS_BLOCK);
             const int nsub = (batch_count + CUGS_WAVE - 1) / CUGS_WAVE;
             for (int sub = nsub - 1; sub >= 0 && !wave_done; --sub) {
                 const int j = sub * CUGS_WAVE + lane;
+                const ActiveRect ar = active_rect(__ballot(!done), qx0, qy0);   // !wave_done => non-empty
                 bool hit = false;
                 if (j < batch_count)
                     hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1],
-                                         s_rec[j * CUGS_REC_F4 + 2], qx0, qy0);
+                                         s_rec[j * CUGS_REC_F4 + 2], ar.x0, ar.y0, ar.wx, ar.wy);
                 unsigned long long mask = __ballot(hit);
-                while (mask) {
-                    const int bit = 63 - __builtin_clzll(mask);             // back to front
-                    mask &= ~(1ull << bit);
-                    const int jj = sub * CUGS_WAVE + bit;
-                    const float4 g0 = s_rec[jj * CUGS_REC_F4 + 0];
-                    const float4 g1 = s_rec[jj * CUGS_REC_F4 + 1];
-                    const float o = s_rec[jj * CUGS_REC_F4 + 2].x;
-                    const float a = g0.z, b = g0.w, c = g1.x;
+                if (ABL == 4) st_tested += min(CUGS_WAVE, batch_count - sub * CUGS_WAVE);
+                if (mask == 0ull) continue;
+                // Software pipeline: the next record's three 16-byte LDS reads are in flight while the
+                // current one is evaluated.  Records are walked back to front (highest bit first).
+                int bit = 63 - __builtin_clzll(mask);
+                mask &= ~(1ull << bit);
+                const float4* rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
+                float4 n0 = rp[0], n1 = rp[1], n2 = rp[2];
+                while (true) {
+                    if (ABL == 4) ++st_steps;
+                    const float4 g0 = n0, g1 = n1, g2 = n2;
+                    const bool more = (mask != 0ull);
+                    if (more) {
+                        bit = 63 - __builtin_clzll(mask);
+                        mask &= ~(1ull << bit);
+                        rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
+                        n0 = rp[0]; n1 = rp[1]; n2 = rp[2];
+                    }
+                    const float a = g0.z, b = g0.w, c = g1.x, o = g2.x;
 
-                    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f, v5 = 0.0f, v6 = 0.0f,
-                          v7 = 0.0f, v8 = 0.0f;
-                    bool contrib = false;
-                    if (ABL != 3 && !done) {
-                        PixelEval e;
-                        if (pixel_alpha(pxf, pyf, g0.x, g0.y, a, b, c, o, e)) {
-                            ++found;
-                            if (found > max_contrib) {
-                                done = true;
-                            } else {
-                                contrib = true;
-                                const float oma = fmaxf(1.0f - e.alpha, 1e-5f);
-                                const float rcp = __builtin_amdgcn_rcpf(oma);
-                                T *= rcp;                                   // T_before = T_after / (1 - alpha)
-                                const float weight = e.alpha * T;
-                                v0 = dC0 * weight;
-                                v1 = dC1 * weight;
-                                v2 = dC2 * weight;
-                                float dL_dalpha = dC0 * fmaf(T, g1.y, -S0 * rcp);
-                                dL_dalpha = fmaf(dC1, fmaf(T, g1.z, -S1 * rcp), dL_dalpha);
-                                dL_dalpha = fmaf(dC2, fmaf(T, g1.w, -S2 * rcp), dL_dalpha);
-                                S0 = fmaf(weight, g1.y, S0);
-                                S1 = fmaf(weight, g1.z, S1);
-                                S2 = fmaf(weight, g1.w, S2);
-                                const bool clamped = (o * e.e >= 0.99f);
-                                v3 = clamped ? 0.0f : dL_dalpha * e.e;
-                                const float dL_dpower = clamped ? 0.0f : dL_dalpha * e.alpha;
-                                v4 = dL_dpower * fmaf(a, e.dx, b * e.dy);
-                                v5 = dL_dpower * fmaf(b, e.dx, c * e.dy);
-                                const float hdp = -0.5f * dL_dpower;
-                                v6 = hdp * e.dx * e.dx;
-                                v7 = -dL_dpower * e.dx * e.dy;
-                                v8 = hdp * e.dy * e.dy;
+                    // ---- decisions: exactly pixel_alpha() + the contributor count (backward.cu:123-145),
+                    // written branch-free; a lane that is done or skips the Gaussian evaluates harmless values
+                    const float dx = pxf - g0.x, dy = pyf - g0.y;
+                    const float gx = fmaf(a, dx, b * dy), gy = fmaf(b, dx, c * dy);
+                    const float power = -0.5f * fmaf(dx, gx, dy * gy);
+                    const bool in_range = (ABL != 3) && !(power > 0.0f) && !(power < -5.6f);
+                    const float e = cugs_expf_core(in_range ? power : 0.0f);
+                    const float alpha = fminf(o * e, 0.99f);
+                    const bool pass = !done && in_range && !(alpha < (1.0f / 255.0f));
+                    found += pass ? 1 : 0;
+                    const bool live = pass && (found <= max_contrib);
+                    done = done || (pass && !live);                       // count exceeded n_contrib: stop
+
+                    const unsigned long long live_mask = __ballot(live);
+                    if (live_mask != 0ull) {                              // wave-uniform
+                        if (ABL == 4) { ++st_contrib; st_lanes += __popcll(live_mask); }
+                        // ---- values (v_rcp_f32 + FMAs; dead lanes produce exact zeros through `al`, `dpw`)
+                        const float al = live ? alpha : 0.0f;
+                        const float rcp = __builtin_amdgcn_rcpf(fmaxf(1.0f - al, 1e-5f));
+                        T = live ? T * rcp : T;                           // T_before = T_after / (1 - alpha)
+                        const float weight = al * T;
+                        float v0 = dC0 * weight, v1 = dC1 * weight, v2 = dC2 * weight;
+                        float dL_dalpha = dC0 * fmaf(T, g1.y, -S0 * rcp);
+                        dL_dalpha = fmaf(dC1, fmaf(T, g1.z, -S1 * rcp), dL_dalpha);
+                        dL_dalpha = fmaf(dC2, fmaf(T, g1.w, -S2 * rcp), dL_dalpha);
+                        S0 = fmaf(weight, g1.y, S0);
+                        S1 = fmaf(weight, g1.z, S1);
+                        S2 = fmaf(weight, g1.w, S2);
+                        const bool open = live && !(o * e >= 0.99f);      // clamp gate (backward.cu:181-191)
+                        float v3 = open ? dL_dalpha * e : 0.0f;
+                        const float dpw = open ? dL_dalpha * al : 0.0f;   // dL/dpower
+                        float v4 = dpw * gx, v5 = dpw * gy;
+                        const float hdp = -0.5f * dpw;
+                        float v6 = hdp * dx * dx, v7 = -dpw * dx * dy, v8 = hdp * dy * dy;
+                        if (ABL == 1) {
+                            asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8));
+                        } else {
+                            const float total = reduce9(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
+                            if (ABL == 2) {
+                                asm volatile("" ::"v"(total));
+                            } else if (my_slot >= 0) {
+                                atomicAdd(&grad_accum[(int64_t)__float_as_int(g2.z) * CUGS_GRAD_STRIDE + my_slot], total);
                             }
                         }
                     }
-                    // wave-uniform from here: all 64 lanes take part in the DPP sums
-                    if (ABL == 1) {
-                        asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8));
-                    } else if (__ballot(contrib) != 0ull) {
-                        // wave-uniform: all 64 lanes take part in the exchange
-                        const float total = reduce9(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
-                        if (ABL == 2) {
-                            asm volatile("" ::"v"(total));
-                        } else if (my_slot >= 0) {
-                            atomicAdd(&grad_accum[(int64_t)s_gidx[jj] * CUGS_GRAD_STRIDE + my_slot], total);
-                        }
-                    }
                     if (__ballot(!done) == 0ull) { wave_done = true; break; }
+                    if (!more) break;
                 }
             }
         }
         // the next iteration's first barrier orders this batch's LDS reads before the re-staging
+    }
+    if (ABL == 4 && lane == 0) {
+        float* st = grad_accum + (int64_t)stats_row * CUGS_GRAD_STRIDE;
+        atomicAdd(&st[0], (float)st_steps); atomicAdd(&st[1], (float)st_contrib); atomicAdd(&st[2], (float)st_lanes);
+        atomicAdd(&st[3], (float)st_batches); atomicAdd(&st[4], (float)st_tested); atomicAdd(&st[5], (float)num_batches);
     }
 }
 
@@ -203,11 +220,12 @@ extern "C" int cugs_rasterize_backward(int width, int height, const float backgr
         const int abl = abl_env ? atoi(abl_env) : 0;
 #define CUGS_LAUNCH_BWD(P, A)                                                                              \
     hipLaunchKernelGGL((k_raster_backward<P, A>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src, \
-                       dL_dcolor, final_T, n_contrib, grad_accum)
+                       dL_dcolor, final_T, n_contrib, grad_accum, n)
         if (packed) {
             if (abl == 1) CUGS_LAUNCH_BWD(true, 1);
             else if (abl == 2) CUGS_LAUNCH_BWD(true, 2);
             else if (abl == 3) CUGS_LAUNCH_BWD(true, 3);
+            else if (abl == 4) CUGS_LAUNCH_BWD(true, 4);
             else CUGS_LAUNCH_BWD(true, 0);
         } else {
             CUGS_LAUNCH_BWD(false, 0);

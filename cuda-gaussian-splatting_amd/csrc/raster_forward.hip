@@ -54,17 +54,29 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
             const int batch_count = min(CUGS_BLOCK, num_in_range - batch * CUGS_BLOCK);
             for (int sub = 0; sub * CUGS_WAVE < batch_count && !wave_done; ++sub) {
                 const int j = sub * CUGS_WAVE + lane;
+                const ActiveRect ar = active_rect(__ballot(!done), qx0, qy0);   // !wave_done => non-empty
                 bool hit = false;
                 if (j < batch_count)
                     hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1],
-                                         s_rec[j * CUGS_REC_F4 + 2], qx0, qy0);
+                                         s_rec[j * CUGS_REC_F4 + 2], ar.x0, ar.y0, ar.wx, ar.wy);
                 unsigned long long mask = __ballot(hit);
-                while (mask) {
-                    const int jj = sub * CUGS_WAVE + __builtin_ctzll(mask);
-                    mask &= mask - 1ull;
-                    const float4 g0 = s_rec[jj * CUGS_REC_F4 + 0];     // wave-uniform address: broadcast
-                    const float4 g1 = s_rec[jj * CUGS_REC_F4 + 1];
-                    const float o = s_rec[jj * CUGS_REC_F4 + 2].x;
+                if (mask == 0ull) continue;
+                // Software pipeline: the next record's LDS reads are in flight while this one is blended.
+                int bit = __builtin_ctzll(mask);                            // front to back
+                mask &= mask - 1ull;
+                const float4* rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
+                float4 n0 = rp[0], n1 = rp[1];
+                float no = rp[2].x;
+                while (true) {
+                    const float4 g0 = n0, g1 = n1;                          // wave-uniform address: broadcast
+                    const float o = no;
+                    const bool more = (mask != 0ull);
+                    if (more) {
+                        bit = __builtin_ctzll(mask);
+                        mask &= mask - 1ull;
+                        rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
+                        n0 = rp[0]; n1 = rp[1]; no = rp[2].x;
+                    }
                     if (!done) {
                         PixelEval e;
                         if (pixel_alpha(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, o, e)) {
@@ -78,6 +90,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
                         }
                     }
                     if (__ballot(!done) == 0ull) { wave_done = true; break; }
+                    if (!more) break;
                 }
             }
         }

@@ -38,3 +38,20 @@ for r in range(a.rounds):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); R.rasterize_forward(out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges, out.gaussian_indices, wl.width, wl.height, st.background, packed=out.packed); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
 print("forward median %.3f ms" % float(np.median(ts)))
+
+# ---- step counters (ABL 4): needs an accumulator with one extra row -> call the C ABI directly
+import ctypes as C
+from cugs_amd._lib import lib
+acc = torch.zeros((wl.n + 1, 16), dtype=torch.float32, device=dev)
+os.environ["CUGS_BWD_ABLATE"] = "4"
+bg = (C.c_float * 3)(0, 0, 0)
+P = lambda t: C.c_void_p(t.data_ptr())
+rc = lib.cugs_rasterize_backward(wl.width, wl.height, bg, P(out.tile_ranges), P(out.gaussian_indices), P(out.means_2d), P(out.cov_2d_inv),
+                                 P(out.rgb), P(out.opacities_act), P(out.packed), P(g), P(out.final_T), P(out.n_contrib), wl.n, P(acc),
+                                 None, None, None, None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+os.environ.pop("CUGS_BWD_ABLATE", None)
+torch.cuda.synchronize()
+st = acc[wl.n].cpu().numpy()
+tiles = ((wl.width + 15) // 16) * ((wl.height + 15) // 16)
+print("rc", rc, "wave-steps %.3g  contributing %.3g (%.0f%%)  lanes/contributing step %.1f  wave-batches walked %.3g of %.3g  records cull-tested %.3g  (pairs x4 waves = %.3g)"
+      % (st[0], st[1], 100 * st[1] / max(st[0], 1), st[2] / max(st[1], 1), st[3], st[5], st[4], 4.0 * out.total_pairs))
