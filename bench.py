@@ -39,6 +39,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_GBS = 6290.0      # same table: 6.29 TB/s measured float4 copy
 
 STAGES = ("project_forward", "sort", "raster_forward", "raster_backward", "project_backward")
+# the kernel that makes up (all but a memset of) each single-kernel stage, as named in profiles/*_pmc_traffic.json
+STAGE_KERNEL = {"project_forward": "k_project_forward<16, true>", "raster_forward": "k_raster_forward<true>",
+                "raster_backward": "k_raster_backward<true, 0>", "project_backward": "k_project_backward<16, true>"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot run
+    inside the timed process); None if no table is present or the kernel is not in it."""
+    import glob
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not tables or kernel is None:
+        return None, None
+    t = json.load(open(tables[-1]))
+    k = t["kernels"].get(kernel)
+    return (k["hbm_bytes_corrected"] if k else None), os.path.basename(tables[-1])
 
 
 def algorithmic_bytes(n, c, p, w, h):
@@ -242,9 +257,10 @@ def main():
             gpu_ms = float(np.mean([ev[0].elapsed_time(ev[-1]) for ev in events]))
             dom = max(stages_ms, key=stages_ms.get)
             ach = alg[dom] / (stages_ms[dom] * 1e-3) / 1e9
+            traffic, table = pmc_traffic(STAGE_KERNEL.get(dom)) if args.config == "config3" else (None, None)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                        "algorithmic_bytes": int(alg[dom]), "ms": round(stages_ms[dom], 4)}
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "traffic_source": table, "algorithmic_bytes": int(alg[dom]), "ms": round(stages_ms[dom], 4)}
             fach = alg["frame"] / (gpu_ms * 1e-3) / 1e9
             frame = {"algorithmic_bytes": int(alg["frame"]), "gpu_ms": round(gpu_ms, 4), "achieved": round(fach, 1),
                      "unit": "GB/s", "frac_of_8TBs": round(fach / HBM_PEAK_GBS, 4),
