@@ -1,0 +1,66 @@
+// adapter_driver.cpp — exercises the C++ host path (cugs_hip_torch) on raw binary inputs written by
+// tests/test_gpu_cpp_adapter.py and writes raw outputs back: render -> render_backward -> FusedAdam.step.
+//   adapter_driver <dir> <n> <C> <width> <height>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "cugs_hip_torch.hpp"
+
+static torch::Tensor load(const std::string& p, std::vector<int64_t> shape) {
+    auto t = torch::empty(shape, torch::kFloat32);
+    FILE* f = fopen(p.c_str(), "rb");
+    if (!f || fread(t.data_ptr<float>(), sizeof(float), t.numel(), f) != static_cast<size_t>(t.numel())) { fprintf(stderr, "cannot read %s\n", p.c_str()); exit(2); }
+    fclose(f);
+    return t.to(torch::kCUDA);
+}
+static void save(const std::string& p, const torch::Tensor& t) {
+    auto c = t.to(torch::kCPU).contiguous();
+    FILE* f = fopen(p.c_str(), "wb");
+    fwrite(c.data_ptr(), c.element_size(), c.numel(), f);
+    fclose(f);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 6) return 1;
+    const std::string d = argv[1];
+    const int64_t n = atoll(argv[2]), C = atoll(argv[3]);
+    const int w = atoi(argv[4]), h = atoi(argv[5]);
+    try {
+        cugs_hip::ModelTensors m{load(d + "/positions.bin", {n, 3}), load(d + "/sh_coeffs.bin", {n, 3, C}),
+                                 load(d + "/opacities.bin", {n, 1}), load(d + "/rotations.bin", {n, 4}),
+                                 load(d + "/scales.bin", {n, 3})};
+        auto camt = load(d + "/camera.bin", {26}).to(torch::kCPU);
+        const float* cf = camt.data_ptr<float>();
+        cugs_camera cam{};
+        for (int i = 0; i < 16; ++i) cam.view[i] = cf[i];
+        cam.fx = cf[16]; cam.fy = cf[17]; cam.cx = cf[18]; cam.cy = cf[19];
+        cam.width = w; cam.height = h;
+        cam.cam_center[0] = cf[20]; cam.cam_center[1] = cf[21]; cam.cam_center[2] = cf[22];
+        cugs_hip::RenderSettings st;
+        st.background[0] = cf[23]; st.background[1] = cf[24]; st.background[2] = cf[25];
+        auto g = load(d + "/dl_dcolor.bin", {h, w, 3});
+
+        auto out = cugs_hip::render(m, cam, st);
+        auto grads = cugs_hip::render_backward(g, out, m, cam, st);
+        cugs_hip::FusedAdam opt({m.positions, m.sh_coeffs, m.opacities, m.scales, m.rotations},
+                                {1.6e-4f, 2.5e-3f, 0.05f, 5e-3f, 1e-3f});
+        opt.apply_gradients(grads);
+        opt.step();
+        save(d + "/out_color.bin", out.color);
+        save(d + "/out_n_contrib.bin", out.n_contrib);
+        save(d + "/out_indices.bin", out.gaussian_indices);
+        save(d + "/out_dpos.bin", grads.dL_dpositions);
+        save(d + "/out_dsh.bin", grads.dL_dsh_coeffs);
+        save(d + "/out_positions_after_adam.bin", m.positions);
+        // the reference's TORCH_CHECK behaviour: a CPU tensor must be rejected with c10::Error
+        bool threw = false;
+        try { cugs_hip::evaluate_sh_cuda(1, torch::zeros({2, 3, 4}), torch::zeros({2, 3})); } catch (const c10::Error&) { threw = true; }
+        printf("adapter_driver ok pairs=%lld torch_check=%d\n", (long long)out.gaussian_indices.numel(), threw ? 1 : 0);
+        return threw ? 0 : 3;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "adapter_driver failed: %s\n", e.what());
+        return 4;
+    }
+}

@@ -1,0 +1,321 @@
+// cugs_hip_torch.cpp — see cugs_hip_torch.hpp.  Each function: validate like the reference's
+// launcher, allocate outputs with torch (the C ABI allocates nothing), pass raw pointers and
+// torch's current HIP stream, turn a non-zero return into std::runtime_error.
+#include "cugs_hip_torch.hpp"
+
+#include <c10/hip/HIPStream.h>
+
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+#include <string>
+
+namespace cugs_hip {
+namespace {
+
+void check(int code, const char* what) {
+    if (code != 0)
+        throw std::runtime_error(std::string("HIP error in ") + what + " - " + cugs_error_string(code));
+}
+void* stream_of(const torch::Tensor& t) {
+    return static_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+}
+torch::Tensor f32c(const torch::Tensor& t) { return t.contiguous().to(torch::kFloat32); }   // projection.cu:240-243
+template <typename T> T* ptr(const torch::Tensor& t) {
+    return (t.defined() && t.numel() > 0) ? t.data_ptr<T>() : nullptr;
+}
+torch::TensorOptions fopt(const torch::Tensor& like) { return torch::TensorOptions().dtype(torch::kFloat32).device(like.device()); }
+torch::TensorOptions iopt(const torch::Tensor& like) { return torch::TensorOptions().dtype(torch::kInt32).device(like.device()); }
+
+torch::Tensor& workspace(const torch::Device& dev, size_t bytes) {     // grow-only, per device
+    static thread_local std::vector<std::pair<torch::Device, torch::Tensor>> pool;
+    for (auto& e : pool)
+        if (e.first == dev) {
+            if (static_cast<size_t>(e.second.numel()) < bytes)
+                e.second = torch::empty({static_cast<int64_t>(bytes + bytes / 4 + 4096)},
+                                        torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+            return e.second;
+        }
+    pool.emplace_back(dev, torch::empty({static_cast<int64_t>(bytes + bytes / 4 + 4096)},
+                                        torch::TensorOptions().dtype(torch::kUInt8).device(dev)));
+    return pool.back().second;
+}
+
+}  // namespace
+
+ProjectionOutput project_gaussians(const torch::Tensor& positions, const torch::Tensor& rotations,
+                                   const torch::Tensor& scales, const torch::Tensor& opacities,
+                                   const torch::Tensor& sh_coeffs, const cugs_camera& camera,
+                                   int active_sh_degree, float scale_modifier) {
+    TORCH_CHECK(positions.is_cuda(), "positions must be on CUDA");
+    TORCH_CHECK(positions.dim() == 2 && positions.size(1) == 3);
+    const int64_t n = positions.size(0);
+    ProjectionOutput o;
+    o.means_2d = torch::empty({n, 2}, fopt(positions));
+    o.depths = torch::empty({n}, fopt(positions));
+    o.cov_2d_inv = torch::empty({n, 3}, fopt(positions));
+    o.radii = torch::empty({n}, iopt(positions));
+    o.tiles_touched = torch::empty({n}, iopt(positions));
+    o.opacities_act = torch::empty({n}, fopt(positions));
+    o.rgb = torch::empty({n, 3}, fopt(positions));
+    o.packed = torch::empty({n, CUGS_PACKED_STRIDE}, fopt(positions));
+    if (n == 0) return o;
+    auto pos = f32c(positions), rot = f32c(rotations), scl = f32c(scales), opa = f32c(opacities), sh = f32c(sh_coeffs);
+    TORCH_CHECK(sh.dim() == 3 && sh.size(0) == n && sh.size(1) == 3, "sh_coeffs must be [N, 3, C]");
+    check(cugs_project_forward(n, static_cast<int>(sh.size(2)), active_sh_degree, ptr<float>(pos), ptr<float>(rot),
+                               ptr<float>(scl), ptr<float>(opa), ptr<float>(sh), &camera, scale_modifier,
+                               ptr<float>(o.means_2d), ptr<float>(o.depths), ptr<float>(o.cov_2d_inv),
+                               ptr<int32_t>(o.radii), ptr<int32_t>(o.tiles_touched), ptr<float>(o.opacities_act),
+                               ptr<float>(o.rgb), ptr<float>(o.packed), stream_of(positions)),
+          "cugs_project_forward");
+    return o;
+}
+
+SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor& depths, const torch::Tensor& radii,
+                             const torch::Tensor& tiles_touched, int img_w, int img_h) {
+    TORCH_CHECK(means_2d.is_cuda(), "means_2d must be on CUDA");
+    const int64_t n = means_2d.size(0);
+    const int num_tiles = ((img_w + CUGS_TILE - 1) / CUGS_TILE) * ((img_h + CUGS_TILE - 1) / CUGS_TILE);
+    SortingOutput o;
+    o.tile_ranges = torch::empty({num_tiles, 2}, iopt(means_2d));
+    void* st = stream_of(means_2d);
+    auto tiles = tiles_touched.contiguous().to(torch::kInt32);
+    int64_t total = 0;
+    if (n > 0) {
+        auto& ws = workspace(means_2d.device(), cugs_sort_workspace_bytes(n, 0, img_w, img_h));
+        check(cugs_sort_count_pairs(n, ptr<int32_t>(tiles), ws.data_ptr(), ws.numel(), &total, st), "cugs_sort_count_pairs");
+    }
+    o.total_pairs = static_cast<int>(total);
+    o.gaussian_keys_sorted = torch::empty({total}, torch::TensorOptions().dtype(torch::kInt64).device(means_2d.device()));
+    o.gaussian_values_sorted = torch::empty({total}, iopt(means_2d));
+    if (num_tiles > 0) {
+        auto& ws = workspace(means_2d.device(), cugs_sort_workspace_bytes(n, total, img_w, img_h));
+        auto m = means_2d.contiguous(), d = depths.contiguous(), r = radii.contiguous();
+        check(cugs_sort_pairs(n, total, ptr<float>(m), ptr<float>(d), ptr<int32_t>(r), ptr<int32_t>(tiles), img_w, img_h,
+                              ws.data_ptr(), ws.numel(), reinterpret_cast<uint64_t*>(ptr<int64_t>(o.gaussian_keys_sorted)),
+                              ptr<int32_t>(o.gaussian_values_sorted), ptr<int32_t>(o.tile_ranges), st),
+              "cugs_sort_pairs");
+    }
+    return o;
+}
+
+ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tensor& cov_2d_inv, const torch::Tensor& rgb,
+                                const torch::Tensor& opacities, const torch::Tensor& tile_ranges,
+                                const torch::Tensor& gaussian_indices, int img_w, int img_h,
+                                const float background[3], const torch::Tensor& packed) {
+    TORCH_CHECK(means_2d.is_cuda(), "means_2d must be on CUDA");
+    ForwardOutput o;
+    o.color = torch::empty({img_h, img_w, 3}, fopt(means_2d));
+    o.final_T = torch::empty({img_h, img_w}, fopt(means_2d));
+    o.n_contrib = torch::empty({img_h, img_w}, iopt(means_2d));
+    if (img_w == 0 || img_h == 0) return o;
+    auto m = means_2d.contiguous(), c = cov_2d_inv.contiguous(), r = rgb.contiguous(), op = opacities.contiguous();
+    auto tr = tile_ranges.contiguous(), gi = gaussian_indices.contiguous();
+    check(cugs_rasterize_forward(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m), ptr<float>(c),
+                                 ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(o.color),
+                                 ptr<float>(o.final_T), ptr<int32_t>(o.n_contrib), stream_of(means_2d)),
+          "cugs_rasterize_forward");
+    return o;
+}
+
+RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const torch::Tensor& means_2d,
+                                           const torch::Tensor& cov_2d_inv, const torch::Tensor& rgb,
+                                           const torch::Tensor& opacities, const torch::Tensor& tile_ranges,
+                                           const torch::Tensor& gaussian_indices, const torch::Tensor& final_T,
+                                           const torch::Tensor& n_contrib, int img_w, int img_h,
+                                           const float background[3], int n_gaussians, const torch::Tensor& packed,
+                                           bool unpack) {
+    TORCH_CHECK(dL_dcolor.is_cuda(), "dL_dcolor must be on CUDA");
+    const int64_t n = n_gaussians;
+    RasterizeBackwardOutput o;
+    o.grad_accum = torch::empty({n, CUGS_GRAD_STRIDE}, fopt(dL_dcolor));
+    if (unpack) {
+        o.dL_drgb = torch::empty({n, 3}, fopt(dL_dcolor));
+        o.dL_dopacity_act = torch::empty({n}, fopt(dL_dcolor));
+        o.dL_dmeans_2d = torch::empty({n, 2}, fopt(dL_dcolor));
+        o.dL_dcov_2d_inv = torch::empty({n, 3}, fopt(dL_dcolor));
+    }
+    if (n == 0) return o;
+    auto g = dL_dcolor.contiguous(), m = means_2d.contiguous(), c = cov_2d_inv.contiguous(), r = rgb.contiguous();
+    auto op = opacities.contiguous(), tr = tile_ranges.contiguous(), gi = gaussian_indices.contiguous();
+    auto ft = final_T.contiguous(), nc = n_contrib.contiguous();
+    check(cugs_rasterize_backward(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m), ptr<float>(c),
+                                  ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(g), ptr<float>(ft),
+                                  ptr<int32_t>(nc), n, ptr<float>(o.grad_accum), ptr<float>(o.dL_drgb),
+                                  ptr<float>(o.dL_dopacity_act), ptr<float>(o.dL_dmeans_2d), ptr<float>(o.dL_dcov_2d_inv),
+                                  stream_of(dL_dcolor)),
+          "cugs_rasterize_backward");
+    return o;
+}
+
+namespace {
+ProjectionBackwardOutput project_backward_impl(const torch::Tensor* accum, const torch::Tensor* rgb_clamped,
+                                               torch::Tensor* d_means_out, const torch::Tensor& gm, const torch::Tensor& gc,
+                                               const torch::Tensor& gr, const torch::Tensor& go,
+                                               const torch::Tensor& positions, const torch::Tensor& rotations,
+                                               const torch::Tensor& scales, const torch::Tensor& opacities,
+                                               const torch::Tensor& sh_coeffs, const torch::Tensor& radii,
+                                               const cugs_camera& camera, int degree, float scale_modifier) {
+    TORCH_CHECK(positions.is_cuda(), "positions must be on CUDA");
+    const int64_t n = positions.size(0);
+    ProjectionBackwardOutput o;
+    o.dL_dpositions = torch::empty({n, 3}, fopt(positions));
+    o.dL_drotations = torch::empty({n, 4}, fopt(positions));
+    o.dL_dscales = torch::empty({n, 3}, fopt(positions));
+    o.dL_dopacities = torch::empty({n, 1}, fopt(positions));
+    auto sh = f32c(sh_coeffs);
+    o.dL_dsh_coeffs = torch::empty_like(sh);
+    if (n == 0) return o;
+    auto pos = f32c(positions), rot = f32c(rotations), scl = f32c(scales), opa = f32c(opacities), rad = radii.contiguous();
+    auto cm = gm.defined() ? gm.contiguous() : gm, cc = gc.defined() ? gc.contiguous() : gc;
+    auto cr = gr.defined() ? gr.contiguous() : gr, co = go.defined() ? go.contiguous() : go;
+    check(cugs_project_backward(n, static_cast<int>(sh.size(2)), degree, ptr<float>(pos), ptr<float>(rot), ptr<float>(scl),
+                                ptr<float>(opa), ptr<float>(sh), ptr<int32_t>(rad),
+                                rgb_clamped ? ptr<float>(*rgb_clamped) : nullptr, &camera, scale_modifier,
+                                accum ? ptr<float>(*accum) : nullptr, ptr<float>(cm), ptr<float>(cc), ptr<float>(cr),
+                                ptr<float>(co), ptr<float>(o.dL_dpositions), ptr<float>(o.dL_drotations),
+                                ptr<float>(o.dL_dscales), ptr<float>(o.dL_dopacities), ptr<float>(o.dL_dsh_coeffs),
+                                d_means_out ? ptr<float>(*d_means_out) : nullptr, stream_of(positions)),
+          "cugs_project_backward");
+    return o;
+}
+}  // namespace
+
+ProjectionBackwardOutput project_backward(const torch::Tensor& dL_dmeans_2d, const torch::Tensor& dL_dcov_2d_inv,
+                                          const torch::Tensor& dL_drgb, const torch::Tensor& dL_dopacity_act,
+                                          const torch::Tensor& positions, const torch::Tensor& rotations,
+                                          const torch::Tensor& scales, const torch::Tensor& opacities,
+                                          const torch::Tensor& sh_coeffs, const torch::Tensor& radii,
+                                          const cugs_camera& camera, int active_sh_degree, float scale_modifier) {
+    return project_backward_impl(nullptr, nullptr, nullptr, dL_dmeans_2d, dL_dcov_2d_inv, dL_drgb, dL_dopacity_act,
+                                 positions, rotations, scales, opacities, sh_coeffs, radii, camera, active_sh_degree,
+                                 scale_modifier);
+}
+
+torch::Tensor evaluate_sh_cuda(int degree, const torch::Tensor& sh_coeffs, const torch::Tensor& directions) {
+    TORCH_CHECK(degree >= 0 && degree <= 3, "SH degree must be 0..3, got ", degree);                 // core/sh.cu:84-97
+    TORCH_CHECK(sh_coeffs.is_cuda(), "sh_coeffs must be on CUDA device");
+    TORCH_CHECK(directions.is_cuda(), "directions must be on CUDA device");
+    TORCH_CHECK(sh_coeffs.dim() == 3 && sh_coeffs.size(1) == 3, "sh_coeffs must be [N, 3, C]");
+    TORCH_CHECK(directions.dim() == 2 && directions.size(1) == 3, "directions must be [N, 3]");
+    TORCH_CHECK(sh_coeffs.size(0) == directions.size(0), "Batch size mismatch");
+    TORCH_CHECK(sh_coeffs.size(2) >= (degree + 1) * (degree + 1), "Need at least ", (degree + 1) * (degree + 1),
+                " coefficients for degree ", degree);
+    auto c = f32c(sh_coeffs), d = f32c(directions);
+    auto out = torch::empty({c.size(0), 3}, fopt(c));
+    if (c.size(0) == 0) return out;
+    check(cugs_evaluate_sh(degree, c.size(0), static_cast<int>(c.size(2)), ptr<float>(c), ptr<float>(d), ptr<float>(out),
+                           stream_of(c)), "cugs_evaluate_sh");
+    return out;
+}
+
+torch::Tensor evaluate_sh_backward_cuda(int degree, const torch::Tensor& sh_coeffs, const torch::Tensor& directions,
+                                        const torch::Tensor& dL_dcolor) {
+    TORCH_CHECK(degree >= 0 && degree <= 3, "SH degree must be 0..3, got ", degree);                 // sh_backward.cu:120-130
+    TORCH_CHECK(sh_coeffs.is_cuda() && directions.is_cuda() && dL_dcolor.is_cuda(), "inputs must be on CUDA device");
+    TORCH_CHECK(sh_coeffs.dim() == 3 && sh_coeffs.size(1) == 3, "sh_coeffs must be [N, 3, C]");
+    TORCH_CHECK(directions.dim() == 2 && directions.size(1) == 3, "directions must be [N, 3]");
+    TORCH_CHECK(dL_dcolor.dim() == 2 && dL_dcolor.size(1) == 3, "dL_dcolor must be [N, 3]");
+    auto c = f32c(sh_coeffs), d = f32c(directions), g = f32c(dL_dcolor);
+    auto out = torch::empty_like(c);
+    if (c.size(0) == 0) return out;
+    check(cugs_evaluate_sh_backward(degree, c.size(0), static_cast<int>(c.size(2)), ptr<float>(c), ptr<float>(d),
+                                    ptr<float>(g), ptr<float>(out), stream_of(c)), "cugs_evaluate_sh_backward");
+    return out;
+}
+
+static int max_sh_degree(const torch::Tensor& sh) {                                                    // gaussian.hpp:47-54
+    return sh.defined() ? static_cast<int>(std::sqrt(static_cast<float>(sh.size(2)))) - 1 : 0;
+}
+
+RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings) {
+    TORCH_CHECK(model.positions.defined() && model.positions.is_cuda(), "GaussianModel must be on CUDA device");
+    const int64_t n = model.positions.size(0);
+    const int w = camera.width, h = camera.height;
+    RenderOutput o;
+    if (n == 0) {                                                                                     // rasterizer.cpp:36-55
+        o.color = torch::empty({h, w, 3}, fopt(model.positions));
+        for (int ch = 0; ch < 3; ++ch) o.color.select(2, ch).fill_(settings.background[ch]);
+        o.final_T = torch::ones({h, w}, fopt(model.positions));
+        o.n_contrib = torch::zeros({h, w}, iopt(model.positions));
+        o.means_2d = torch::empty({0, 2}, fopt(model.positions)); o.depths = torch::empty({0}, fopt(model.positions));
+        o.cov_2d_inv = torch::empty({0, 3}, fopt(model.positions)); o.radii = torch::empty({0}, iopt(model.positions));
+        o.rgb = torch::empty({0, 3}, fopt(model.positions)); o.opacities_act = torch::empty({0}, fopt(model.positions));
+        o.gaussian_indices = torch::empty({0}, iopt(model.positions)); o.tile_ranges = torch::empty({0, 2}, iopt(model.positions));
+        return o;
+    }
+    const int degree = std::min(settings.active_sh_degree, max_sh_degree(model.sh_coeffs));
+    auto proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, camera,
+                                  degree, settings.scale_modifier);
+    auto srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
+    auto fwd = rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
+                                 srt.gaussian_values_sorted, w, h, settings.background, proj.packed);
+    o.color = fwd.color; o.final_T = fwd.final_T; o.n_contrib = fwd.n_contrib;
+    o.means_2d = proj.means_2d; o.depths = proj.depths; o.cov_2d_inv = proj.cov_2d_inv; o.radii = proj.radii;
+    o.rgb = proj.rgb; o.opacities_act = proj.opacities_act;
+    o.gaussian_indices = srt.gaussian_values_sorted; o.tile_ranges = srt.tile_ranges; o.packed = proj.packed;
+    return o;
+}
+
+BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutput& ro, const ModelTensors& model,
+                               const cugs_camera& camera, const RenderSettings& settings) {
+    TORCH_CHECK(dL_dcolor.is_cuda(), "dL_dcolor must be on CUDA device");                             // rasterizer.cpp:122-124
+    TORCH_CHECK(dL_dcolor.dim() == 3 && dL_dcolor.size(2) == 3, "dL_dcolor must be [H, W, 3]");
+    const int64_t n = model.positions.size(0);
+    BackwardOutput o;
+    if (n == 0) {                                                                                     // rasterizer.cpp:130-139
+        o.dL_dpositions = torch::zeros({0, 3}, fopt(dL_dcolor)); o.dL_drotations = torch::zeros({0, 4}, fopt(dL_dcolor));
+        o.dL_dscales = torch::zeros({0, 3}, fopt(dL_dcolor)); o.dL_dopacities = torch::zeros({0, 1}, fopt(dL_dcolor));
+        o.dL_dsh_coeffs = torch::zeros_like(model.sh_coeffs); o.dL_dmeans_2d = torch::zeros({0, 2}, fopt(dL_dcolor));
+        return o;
+    }
+    const int degree = std::min(settings.active_sh_degree, max_sh_degree(model.sh_coeffs));
+    auto rb = rasterize_backward(dL_dcolor, ro.means_2d, ro.cov_2d_inv, ro.rgb, ro.opacities_act, ro.tile_ranges,
+                                 ro.gaussian_indices, ro.final_T, ro.n_contrib, camera.width, camera.height,
+                                 settings.background, static_cast<int>(n), ro.packed, /*unpack=*/false);
+    o.dL_dmeans_2d = torch::empty({n, 2}, fopt(dL_dcolor));
+    auto pb = project_backward_impl(&rb.grad_accum, &ro.rgb, &o.dL_dmeans_2d, {}, {}, {}, {}, model.positions,
+                                    model.rotations, model.scales, model.opacities, model.sh_coeffs, ro.radii, camera, degree,
+                                    settings.scale_modifier);
+    o.dL_dpositions = pb.dL_dpositions; o.dL_drotations = pb.dL_drotations; o.dL_dscales = pb.dL_dscales;
+    o.dL_dopacities = pb.dL_dopacities; o.dL_dsh_coeffs = pb.dL_dsh_coeffs;
+    return o;
+}
+
+FusedAdam::FusedAdam(std::array<torch::Tensor, 5> params, std::array<float, 5> lrs, AdamHyper h)
+    : params_(std::move(params)), lrs_(lrs), h_(h) {
+    for (int i = 0; i < 5; ++i) { m_[i] = torch::zeros_like(params_[i]); v_[i] = torch::zeros_like(params_[i]); }
+}
+void FusedAdam::apply_gradients(const BackwardOutput& g) {        // references, no copy (fused_adam.cu:113-120)
+    grads_ = {g.dL_dpositions, g.dL_dsh_coeffs, g.dL_dopacities, g.dL_dscales, g.dL_drotations};
+}
+void FusedAdam::zero_grad() { for (auto& g : grads_) g = torch::Tensor(); }
+void FusedAdam::step() {
+    ++step_count_;
+    float bc1, bc2;
+    cugs_adam_bias_correction(h_.beta1, h_.beta2, step_count_, &bc1, &bc2);
+    cugs_adam_group groups[5];
+    std::array<torch::Tensor, 5> pc, gc, mc, vc;
+    void* st = nullptr;
+    for (int i = 0; i < 5; ++i) {
+        groups[i] = cugs_adam_group{nullptr, nullptr, nullptr, nullptr, 0, lrs_[i], 0.f};
+        if (!grads_[i].defined()) continue;                       // fused_adam.cu:156
+        TORCH_CHECK(params_[i].is_cuda(), "FusedAdam: param must be on CUDA");
+        TORCH_CHECK(grads_[i].is_cuda(), "FusedAdam: grad must be on CUDA");
+        TORCH_CHECK(params_[i].numel() == grads_[i].numel(), "FusedAdam: param/grad size mismatch: ", params_[i].numel(),
+                    " vs ", grads_[i].numel());
+        pc[i] = params_[i].contiguous(); gc[i] = grads_[i].contiguous(); mc[i] = m_[i].contiguous(); vc[i] = v_[i].contiguous();
+        groups[i].param = pc[i].data_ptr<float>(); groups[i].grad = gc[i].data_ptr<float>();
+        groups[i].m = mc[i].data_ptr<float>(); groups[i].v = vc[i].data_ptr<float>(); groups[i].n = pc[i].numel();
+        st = stream_of(params_[i]);
+    }
+    check(cugs_fused_adam_groups(groups, 5, h_.beta1, h_.beta2, h_.eps, bc1, bc2, st), "cugs_fused_adam_groups");
+    for (int i = 0; i < 5; ++i) {                                 // fused_adam.cu:216-218
+        if (!grads_[i].defined()) continue;
+        if (!params_[i].is_contiguous()) params_[i].copy_(pc[i]);
+        if (!m_[i].is_contiguous()) m_[i].copy_(mc[i]);
+        if (!v_[i].is_contiguous()) v_[i].copy_(vc[i]);
+    }
+}
+
+}  // namespace cugs_hip

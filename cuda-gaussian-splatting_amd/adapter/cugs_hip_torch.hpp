@@ -1,0 +1,95 @@
+// cugs_hip_torch.hpp — libtorch layer over the C ABI (include/cugs_hip.h).
+//
+// C++ host side of the drop-in: the reference's stage functions and render()/render_backward()
+// with torch::Tensor arguments and results (same names, shapes, dtypes and zero/empty-case
+// behaviour as namespace cugs), the camera as the POD `cugs_camera`.  It depends on libtorch
+// only; `reference_glue.hpp` adds the few lines that map cugs::CameraInfo / cugs::GaussianModel
+// (Eigen + the reference's headers) onto it.  Errors: non-zero C-ABI codes become
+// std::runtime_error like CUDA_CHECK (utils/cuda_utils.cuh:12-20); argument checks are TORCH_CHECK.
+#pragma once
+
+#include <torch/torch.h>
+
+#include <array>
+
+#include "../../include/cugs_hip.h"
+
+namespace cugs_hip {
+
+struct ProjectionOutput {          // rasterizer/projection.hpp
+    torch::Tensor means_2d, depths, cov_2d_inv, radii, tiles_touched, rgb, opacities_act;
+    torch::Tensor packed;          // [N,12] scratch for the blend kernels (not in the reference)
+};
+struct SortingOutput {             // rasterizer/sorting.hpp:18-24
+    torch::Tensor gaussian_keys_sorted, gaussian_values_sorted, tile_ranges;
+    int total_pairs = 0;
+};
+struct ForwardOutput { torch::Tensor color, final_T, n_contrib; };
+struct RasterizeBackwardOutput {
+    torch::Tensor dL_drgb, dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv;
+    torch::Tensor grad_accum;      // [N,16] packed rows (not in the reference)
+};
+struct ProjectionBackwardOutput { torch::Tensor dL_dpositions, dL_drotations, dL_dscales, dL_dopacities, dL_dsh_coeffs; };
+
+struct ModelTensors {              // the five tensors of cugs::GaussianModel (core/gaussian.hpp:34-40)
+    torch::Tensor positions, sh_coeffs, opacities, rotations, scales;
+};
+struct RenderSettings { float background[3] = {0.f, 0.f, 0.f}; int active_sh_degree = 3; float scale_modifier = 1.f; };
+struct RenderOutput {              // rasterizer/rasterizer.hpp:27-46
+    torch::Tensor color, final_T, n_contrib, means_2d, depths, cov_2d_inv, radii, rgb, opacities_act,
+        gaussian_indices, tile_ranges;
+    torch::Tensor packed;
+};
+struct BackwardOutput { torch::Tensor dL_dpositions, dL_drotations, dL_dscales, dL_dopacities, dL_dsh_coeffs, dL_dmeans_2d; };
+
+ProjectionOutput project_gaussians(const torch::Tensor& positions, const torch::Tensor& rotations,
+                                   const torch::Tensor& scales, const torch::Tensor& opacities,
+                                   const torch::Tensor& sh_coeffs, const cugs_camera& camera,
+                                   int active_sh_degree, float scale_modifier = 1.0f);
+SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor& depths, const torch::Tensor& radii,
+                             const torch::Tensor& tiles_touched, int img_w, int img_h);
+ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tensor& cov_2d_inv,
+                                const torch::Tensor& rgb, const torch::Tensor& opacities,
+                                const torch::Tensor& tile_ranges, const torch::Tensor& gaussian_indices,
+                                int img_w, int img_h, const float background[3],
+                                const torch::Tensor& packed = {});
+RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const torch::Tensor& means_2d,
+                                           const torch::Tensor& cov_2d_inv, const torch::Tensor& rgb,
+                                           const torch::Tensor& opacities, const torch::Tensor& tile_ranges,
+                                           const torch::Tensor& gaussian_indices, const torch::Tensor& final_T,
+                                           const torch::Tensor& n_contrib, int img_w, int img_h,
+                                           const float background[3], int n_gaussians,
+                                           const torch::Tensor& packed = {}, bool unpack = true);
+ProjectionBackwardOutput project_backward(const torch::Tensor& dL_dmeans_2d, const torch::Tensor& dL_dcov_2d_inv,
+                                          const torch::Tensor& dL_drgb, const torch::Tensor& dL_dopacity_act,
+                                          const torch::Tensor& positions, const torch::Tensor& rotations,
+                                          const torch::Tensor& scales, const torch::Tensor& opacities,
+                                          const torch::Tensor& sh_coeffs, const torch::Tensor& radii,
+                                          const cugs_camera& camera, int active_sh_degree,
+                                          float scale_modifier = 1.0f);
+torch::Tensor evaluate_sh_cuda(int degree, const torch::Tensor& sh_coeffs, const torch::Tensor& directions);
+torch::Tensor evaluate_sh_backward_cuda(int degree, const torch::Tensor& sh_coeffs, const torch::Tensor& directions,
+                                        const torch::Tensor& dL_dcolor);
+
+RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings);
+BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutput& render_out,
+                               const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings);
+
+// optimizer/fused_adam.hpp:29-106 on raw tensors (group order: positions, sh, opacities, scales, rotations)
+struct AdamHyper { float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-15f; };
+class FusedAdam {
+public:
+    FusedAdam(std::array<torch::Tensor, 5> params, std::array<float, 5> lrs, AdamHyper h = {});
+    void apply_gradients(const BackwardOutput& grads);
+    void zero_grad();
+    void set_lr(int group, float lr) { lrs_[group] = lr; }
+    float get_lr(int group) const { return lrs_[group]; }
+    void step();
+private:
+    std::array<torch::Tensor, 5> params_, m_, v_, grads_;
+    std::array<float, 5> lrs_;
+    AdamHyper h_;
+    int step_count_ = 0;
+};
+
+}  // namespace cugs_hip
