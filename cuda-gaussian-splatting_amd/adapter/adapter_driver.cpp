@@ -23,11 +23,13 @@ static void save(const std::string& p, const torch::Tensor& t) {
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     if (argc < 6) return 1;
     const std::string d = argv[1];
     const int64_t n = atoll(argv[2]), C = atoll(argv[3]);
     const int w = atoi(argv[4]), h = atoi(argv[5]);
     try {
+        fprintf(stderr, "[driver] start\n");
         cugs_hip::ModelTensors m{load(d + "/positions.bin", {n, 3}), load(d + "/sh_coeffs.bin", {n, 3, C}),
                                  load(d + "/opacities.bin", {n, 1}), load(d + "/rotations.bin", {n, 4}),
                                  load(d + "/scales.bin", {n, 3})};
@@ -42,12 +44,16 @@ int main(int argc, char** argv) {
         st.background[0] = cf[23]; st.background[1] = cf[24]; st.background[2] = cf[25];
         auto g = load(d + "/dl_dcolor.bin", {h, w, 3});
 
+        fprintf(stderr, "[driver] inputs loaded\n");
         auto out = cugs_hip::render(m, cam, st);
+        fprintf(stderr, "[driver] render done\n");
         auto grads = cugs_hip::render_backward(g, out, m, cam, st);
+        fprintf(stderr, "[driver] backward done\n");
         cugs_hip::FusedAdam opt({m.positions, m.sh_coeffs, m.opacities, m.scales, m.rotations},
                                 {1.6e-4f, 2.5e-3f, 0.05f, 5e-3f, 1e-3f});
         opt.apply_gradients(grads);
         opt.step();
+        fprintf(stderr, "[driver] adam done\n");
         save(d + "/out_color.bin", out.color);
         save(d + "/out_n_contrib.bin", out.n_contrib);
         save(d + "/out_indices.bin", out.gaussian_indices);
@@ -58,6 +64,7 @@ int main(int argc, char** argv) {
         bool threw = false;
         try { cugs_hip::evaluate_sh_cuda(1, torch::zeros({2, 3, 4}), torch::zeros({2, 3})); } catch (const c10::Error&) { threw = true; }
         printf("adapter_driver ok pairs=%lld torch_check=%d\n", (long long)out.gaussian_indices.numel(), threw ? 1 : 0);
+        fflush(stdout);
         return threw ? 0 : 3;
     } catch (const std::exception& e) {
         fprintf(stderr, "adapter_driver failed: %s\n", e.what());

@@ -7,8 +7,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <tuple>
+#include <vector>
 
 namespace cugs_hip {
 namespace {
@@ -27,18 +31,20 @@ template <typename T> T* ptr(const torch::Tensor& t) {
 torch::TensorOptions fopt(const torch::Tensor& like) { return torch::TensorOptions().dtype(torch::kFloat32).device(like.device()); }
 torch::TensorOptions iopt(const torch::Tensor& like) { return torch::TensorOptions().dtype(torch::kInt32).device(like.device()); }
 
-torch::Tensor& workspace(const torch::Device& dev, size_t bytes) {     // grow-only, per device
-    static thread_local std::vector<std::pair<torch::Device, torch::Tensor>> pool;
+// Returns a handle BY VALUE: a reference into the pool would dangle when a later call grows the vector.
+torch::Tensor workspace(const torch::Device& dev, size_t bytes, int kind) {      // grow-only, per device and kind
+    // intentionally leaked: device tensors must not be destroyed during static destruction, after the
+    // HIP caching allocator has gone away
+    static thread_local auto& pool = *new std::vector<std::tuple<torch::Device, int, torch::Tensor>>();
+    auto make = [&] { return torch::empty({static_cast<int64_t>(bytes + bytes / 4 + 4096)},
+                                          torch::TensorOptions().dtype(torch::kUInt8).device(dev)); };
     for (auto& e : pool)
-        if (e.first == dev) {
-            if (static_cast<size_t>(e.second.numel()) < bytes)
-                e.second = torch::empty({static_cast<int64_t>(bytes + bytes / 4 + 4096)},
-                                        torch::TensorOptions().dtype(torch::kUInt8).device(dev));
-            return e.second;
+        if (std::get<0>(e) == dev && std::get<1>(e) == kind) {
+            if (static_cast<size_t>(std::get<2>(e).numel()) < bytes) std::get<2>(e) = make();
+            return std::get<2>(e);
         }
-    pool.emplace_back(dev, torch::empty({static_cast<int64_t>(bytes + bytes / 4 + 4096)},
-                                        torch::TensorOptions().dtype(torch::kUInt8).device(dev)));
-    return pool.back().second;
+    pool.emplace_back(dev, kind, make());
+    return std::get<2>(pool.back());
 }
 
 }  // namespace
@@ -80,19 +86,20 @@ SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor&
     o.tile_ranges = torch::empty({num_tiles, 2}, iopt(means_2d));
     void* st = stream_of(means_2d);
     auto tiles = tiles_touched.contiguous().to(torch::kInt32);
+    auto m = means_2d.contiguous(), d = depths.contiguous(), r = radii.contiguous();
+    auto ws = workspace(means_2d.device(), cugs_sort_workspace_bytes(n), 0);
     int64_t total = 0;
-    if (n > 0) {
-        auto& ws = workspace(means_2d.device(), cugs_sort_workspace_bytes(n, 0, img_w, img_h));
-        check(cugs_sort_count_pairs(n, ptr<int32_t>(tiles), ws.data_ptr(), ws.numel(), &total, st), "cugs_sort_count_pairs");
-    }
+    if (n > 0)
+        check(cugs_sort_count_pairs(n, ptr<float>(m), ptr<float>(d), ptr<int32_t>(r), ptr<int32_t>(tiles), img_w, img_h,
+                                    ws.data_ptr(), ws.numel(), &total, st), "cugs_sort_count_pairs");
     o.total_pairs = static_cast<int>(total);
     o.gaussian_keys_sorted = torch::empty({total}, torch::TensorOptions().dtype(torch::kInt64).device(means_2d.device()));
     o.gaussian_values_sorted = torch::empty({total}, iopt(means_2d));
     if (num_tiles > 0) {
-        auto& ws = workspace(means_2d.device(), cugs_sort_workspace_bytes(n, total, img_w, img_h));
-        auto m = means_2d.contiguous(), d = depths.contiguous(), r = radii.contiguous();
+        auto wp = workspace(means_2d.device(), cugs_sort_pair_workspace_bytes(total), 1);
         check(cugs_sort_pairs(n, total, ptr<float>(m), ptr<float>(d), ptr<int32_t>(r), ptr<int32_t>(tiles), img_w, img_h,
-                              ws.data_ptr(), ws.numel(), reinterpret_cast<uint64_t*>(ptr<int64_t>(o.gaussian_keys_sorted)),
+                              ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(),
+                              reinterpret_cast<uint64_t*>(ptr<int64_t>(o.gaussian_keys_sorted)),
                               ptr<int32_t>(o.gaussian_values_sorted), ptr<int32_t>(o.tile_ranges), st),
               "cugs_sort_pairs");
     }
@@ -245,9 +252,12 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         return o;
     }
     const int degree = std::min(settings.active_sh_degree, max_sh_degree(model.sh_coeffs));
+    if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] render: n=%lld degree=%d\n", (long long)n, degree);
     auto proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, camera,
                                   degree, settings.scale_modifier);
+    if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] projected\n");
     auto srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
+    if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] sorted P=%d\n", srt.total_pairs);
     auto fwd = rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
                                  srt.gaussian_values_sorted, w, h, settings.background, proj.packed);
     o.color = fwd.color; o.final_T = fwd.final_T; o.n_contrib = fwd.n_contrib;

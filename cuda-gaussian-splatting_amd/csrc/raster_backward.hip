@@ -70,7 +70,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     bool done = !inside || max_contrib <= 0;
     bool wave_done = (__ballot(!done) == 0ull);
     const int my_slot = reduce9_slot(lane);
-    unsigned st_steps = 0, st_contrib = 0, st_lanes = 0, st_batches = 0, st_tested = 0;   // ABL == 4 only
+    unsigned st_steps = 0, st_contrib = 0, st_lanes = 0, st_batches = 0, st_tested = 0, st_sub = 0, st_open = 0;   // ABL == 4 only
 
     for (int batch = num_batches - 1; batch >= 0; --batch) {
         if (lane == 0) s_wave_done[wave] = wave_done ? 1 : 0;
@@ -127,7 +127,14 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
 
                     const unsigned long long live_mask = __ballot(live);
                     if (live_mask != 0ull) {                              // wave-uniform
-                        if (ABL == 4) { ++st_contrib; st_lanes += __popcll(live_mask); }
+                        if (ABL == 4) {
+                            ++st_contrib; st_lanes += __popcll(live_mask);
+                            // 4x4 sub-blocks of the 8x8 quad (lane = y*8+x) holding a contributing pixel
+                            const unsigned long long left = 0x0F0F0F0F0F0F0F0Full;
+                            st_sub += ((live_mask & left & 0xFFFFFFFFull) != 0) + ((live_mask & ~left & 0xFFFFFFFFull) != 0) +
+                                      ((live_mask & left & ~0xFFFFFFFFull) != 0) + ((live_mask & ~left & ~0xFFFFFFFFull) != 0);
+                            st_open += __popcll(__ballot(!done));
+                        }
                         // ---- values (v_rcp_f32 + FMAs; dead lanes produce exact zeros through `al`, `dpw`)
                         const float al = live ? alpha : 0.0f;
                         const float rcp = __builtin_amdgcn_rcpf(fmaxf(1.0f - al, 1e-5f));
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         float* st = grad_accum + (int64_t)stats_row * CUGS_GRAD_STRIDE;
         atomicAdd(&st[0], (float)st_steps); atomicAdd(&st[1], (float)st_contrib); atomicAdd(&st[2], (float)st_lanes);
         atomicAdd(&st[3], (float)st_batches); atomicAdd(&st[4], (float)st_tested); atomicAdd(&st[5], (float)num_batches);
+        atomicAdd(&st[6], (float)st_sub); atomicAdd(&st[7], (float)st_open);
     }
 }
 

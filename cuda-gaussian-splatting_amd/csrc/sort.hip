@@ -26,42 +26,53 @@ constexpr int FILL_CHUNK = CUGS_BLOCK;            // Gaussians per workgroup in 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline uint32_t nblocks_for(int64_t count, int chunk) { return (uint32_t)((count + chunk - 1) / chunk); }
 
-struct SortWs {
-    unsigned long long* total;   // pair-count accumulator
+// Two caller-owned scratch buffers.  The N-level one is filled by cugs_sort_count_pairs (depth order,
+// scanned block sums, pair total) and read by cugs_sort_pairs; the pair-level one can only be sized
+// once the pair count is known.
+struct SortWsN {
+    unsigned long long* total;   // [0] pair total (u64), dword 4: zero-pair counter (quirk Q12)
     uint32_t* dkey[2];           // depth bits, ping-pong              [n]
     uint32_t* dval[2];           // Gaussian index, ping-pong          [n]
-    uint32_t* hist;              // [RADIX][nblk] digit-major
     uint32_t* tot;               // [RADIX]
-    uint32_t* blocksum;          // per FILL_CHUNK block pair counts   [nfill + 1]
+    uint32_t* blocksum;          // per FILL_CHUNK block pair counts   [nfill + 2]
+    uint32_t* hist;              // [RADIX][nblk_n] digit-major
+    size_t bytes;
+};
+struct SortWsP {
     uint32_t* ptile[2];          // tile id per pair, ping-pong        [P]
-    uint32_t* pidx[2];           // Gaussian index per pair            [P] (second one only if needed)
+    uint32_t* pidx[2];           // Gaussian index per pair            [P]
+    uint32_t* hist;              // [RADIX][nblk_p]
     size_t bytes;
 };
 
-SortWs carve(void* base, int64_t n, int64_t max_pairs) {
-    SortWs w;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    char* b = static_cast<char*>(base);
-    const uint32_t nblk_n = nblocks_for(n, CHUNK), nblk_p = nblocks_for(max_pairs, CHUNK);
-    const uint32_t nblk = nblk_n > nblk_p ? nblk_n : nblk_p;
-    size_t o_total = take(256);
-    size_t o_dk0 = take(sizeof(uint32_t) * (size_t)n), o_dk1 = take(sizeof(uint32_t) * (size_t)n);
-    size_t o_dv0 = take(sizeof(uint32_t) * (size_t)n), o_dv1 = take(sizeof(uint32_t) * (size_t)n);
-    size_t o_hist = take(sizeof(uint32_t) * (size_t)RADIX * (nblk + 1));
-    size_t o_tot = take(sizeof(uint32_t) * RADIX);
-    size_t o_bs = take(sizeof(uint32_t) * ((size_t)nblocks_for(n, FILL_CHUNK) + 2));
-    size_t o_pt0 = take(sizeof(uint32_t) * (size_t)max_pairs), o_pt1 = take(sizeof(uint32_t) * (size_t)max_pairs);
-    size_t o_pi0 = take(sizeof(uint32_t) * (size_t)max_pairs), o_pi1 = take(sizeof(uint32_t) * (size_t)max_pairs);
-    w.bytes = off;
-    w.total = reinterpret_cast<unsigned long long*>(b + o_total);
-    w.dkey[0] = reinterpret_cast<uint32_t*>(b + o_dk0); w.dkey[1] = reinterpret_cast<uint32_t*>(b + o_dk1);
-    w.dval[0] = reinterpret_cast<uint32_t*>(b + o_dv0); w.dval[1] = reinterpret_cast<uint32_t*>(b + o_dv1);
-    w.hist = reinterpret_cast<uint32_t*>(b + o_hist);
-    w.tot = reinterpret_cast<uint32_t*>(b + o_tot);
-    w.blocksum = reinterpret_cast<uint32_t*>(b + o_bs);
-    w.ptile[0] = reinterpret_cast<uint32_t*>(b + o_pt0); w.ptile[1] = reinterpret_cast<uint32_t*>(b + o_pt1);
-    w.pidx[0] = reinterpret_cast<uint32_t*>(b + o_pi0); w.pidx[1] = reinterpret_cast<uint32_t*>(b + o_pi1);
+struct Carver {
+    char* base; size_t off = 0;
+    template <typename T> T* take(size_t count) {
+        size_t o = off;
+        off = align_up(off + sizeof(T) * count, 256);
+        return reinterpret_cast<T*>(base + o);
+    }
+};
+
+SortWsN carve_n(void* base, int64_t n) {
+    Carver c{static_cast<char*>(base)};
+    SortWsN w;
+    w.total = c.take<unsigned long long>(32);
+    for (int i = 0; i < 2; ++i) w.dkey[i] = c.take<uint32_t>((size_t)n);
+    for (int i = 0; i < 2; ++i) w.dval[i] = c.take<uint32_t>((size_t)n);
+    w.tot = c.take<uint32_t>(RADIX);
+    w.blocksum = c.take<uint32_t>((size_t)nblocks_for(n, FILL_CHUNK) + 2);
+    w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, CHUNK) + 1));
+    w.bytes = c.off;
+    return w;
+}
+SortWsP carve_p(void* base, int64_t pairs) {
+    Carver c{static_cast<char*>(base)};
+    SortWsP w;
+    for (int i = 0; i < 2; ++i) w.ptile[i] = c.take<uint32_t>((size_t)pairs);
+    for (int i = 0; i < 2; ++i) w.pidx[i] = c.take<uint32_t>((size_t)pairs);
+    w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(pairs, CHUNK) + 1));
+    w.bytes = c.off;
     return w;
 }
 
@@ -90,23 +101,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     if (total) *total = w0 + w1 + w2 + w3;
     __syncthreads();
     return base + inc - v;
-}
-
-// ------------------------------------------------------------------------------------
-// sum(tiles_touched): the reference's cumsum[-1].item() (sorting.cu:145-146)
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CUGS_BLOCK) void k_sum_tiles(int64_t n, const int32_t* __restrict__ tiles,
-                                                          unsigned long long* total) {
-    unsigned long long acc = 0;
-    for (int64_t i = (int64_t)blockIdx.x * CUGS_BLOCK + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * CUGS_BLOCK)
-        acc += (unsigned long long)(uint32_t)tiles[i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    __shared__ unsigned long long s_part[4];
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(total, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
 // Reference quirk Q12: a splat whose tile rectangle is empty in both axes still has
@@ -280,19 +274,21 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_blocksums(uint32_t n,
     if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
 }
 
-// Single workgroup: exclusive scan of blocksum[0..nb) in place; blocksum[nb] = grand total.
-__global__ __launch_bounds__(CUGS_BLOCK) void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb) {
+// Single workgroup: exclusive scan of blocksum[0..nb) in place; *total = the 64-bit grand total =
+// sum(tiles_touched), the reference's cumsum[-1].item() (sorting.cu:145-146).
+__global__ __launch_bounds__(CUGS_BLOCK) void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb,
+                                                               unsigned long long* __restrict__ total) {
     __shared__ uint32_t s_tmp[4];
-    uint32_t carry = 0;
+    unsigned long long carry = 0;
     for (uint32_t base = 0; base < nb; base += CUGS_BLOCK) {
         uint32_t i = base + threadIdx.x;
         uint32_t v = i < nb ? blocksum[i] : 0u;
-        uint32_t total;
-        uint32_t ex = block_exclusive_scan(v, s_tmp, &total);
-        if (i < nb) blocksum[i] = carry + ex;
-        carry += total;
+        uint32_t chunk_total;
+        uint32_t ex = block_exclusive_scan(v, s_tmp, &chunk_total);
+        if (i < nb) blocksum[i] = (uint32_t)carry + ex;     // valid whenever the total fits int32 (checked on the host)
+        carry += chunk_total;
     }
-    if (threadIdx.x == 0) blocksum[nb] = carry;
+    if (threadIdx.x == 0) *total = carry;
 }
 
 // k_fill_sort_pairs (sorting.cu:30-72), walked in depth order; only the tile id and the index are
@@ -392,16 +388,16 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t total_pairs
 
 template <bool SRC_DEPTH>
 int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t count, int shift, int bits,
-               const SortWs& ws, uint32_t* kout, uint32_t* vout, hipStream_t st) {
+               uint32_t* hist, uint32_t* tot, uint32_t* kout, uint32_t* vout, hipStream_t st) {
     const uint32_t nblk = nblocks_for(count, CHUNK);
     const uint32_t mask = (1u << bits) - 1u;
     hipLaunchKernelGGL((k_radix_hist<SRC_DEPTH>), dim3(nblk), dim3(CUGS_BLOCK), 0, st, kin, count, shift,
-                       mask, ws.hist, nblk);
+                       mask, hist, nblk);
     CUGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, ws.hist, nblk, ws.tot);
+    hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, hist, nblk, tot);
     CUGS_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_radix_scatter<SRC_DEPTH>), dim3(nblk), dim3(CUGS_BLOCK), 0, st, kin, vin, count,
-                       shift, mask, ws.hist, ws.tot, nblk, kout, vout);
+                       shift, mask, hist, tot, nblk, kout, vout);
     CUGS_LAUNCH_CHECK();
     return 0;
 }
@@ -414,28 +410,54 @@ int tile_bits(int tiles) {
 
 }  // namespace
 
-extern "C" size_t cugs_sort_workspace_bytes(int64_t n, int64_t max_pairs, int width, int height) {
-    (void)width; (void)height;
-    if (n < 0 || max_pairs < 0) return 0;
-    return carve(nullptr, n, max_pairs).bytes;
+extern "C" size_t cugs_sort_workspace_bytes(int64_t n) {
+    if (n < 0) return 0;
+    return carve_n(nullptr, n).bytes;
 }
 
-extern "C" int cugs_sort_count_pairs(int64_t n, const int32_t* tiles_touched, void* workspace,
-                                     size_t workspace_bytes, int64_t* total_pairs_host, void* stream) {
-    if (n < 0 || !total_pairs_host) return CUGS_EINVAL;
+extern "C" size_t cugs_sort_pair_workspace_bytes(int64_t total_pairs) {
+    if (total_pairs < 0) return 0;
+    return carve_p(nullptr, total_pairs).bytes;
+}
+
+// Everything that does not depend on the pair count runs BEFORE the blocking read-back, so the
+// device is busy (depth keys, the 4-pass depth sort, per-block pair sums and their scan) while the
+// host waits for the 8-byte total - the reference idles on cumsum[-1].item() instead (sorting.cu:146).
+extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const float* depths,
+                                     const int32_t* radii, const int32_t* tiles_touched, int width,
+                                     int height, void* workspace, size_t workspace_bytes,
+                                     int64_t* total_pairs_host, void* stream) {
+    if (n < 0 || width < 0 || height < 0 || !total_pairs_host) return CUGS_EINVAL;
     *total_pairs_host = 0;
     if (n == 0) return 0;
-    if (!tiles_touched || !workspace) return CUGS_EINVAL;
-    if (workspace_bytes < 256) return CUGS_EWORKSPACE;
+    if (n > 2147483647ll) return CUGS_EOVERFLOW;
+    if (!means_2d || !depths || !radii || !tiles_touched || !workspace) return CUGS_EINVAL;
+    SortWsN ws = carve_n(workspace, n);
+    if (workspace_bytes < ws.bytes) return CUGS_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    unsigned long long* total = static_cast<unsigned long long*>(workspace);
-    CUGS_RETURN_IF_HIP(hipMemsetAsync(total, 0, sizeof(unsigned long long), st));
-    const int64_t want = (n + CUGS_BLOCK - 1) / CUGS_BLOCK;
-    const int grid = (int)(want < 256 ? want : 256);   // one u64 atomic per workgroup on a single word
-    hipLaunchKernelGGL(k_sum_tiles, dim3(grid), dim3(CUGS_BLOCK), 0, st, n, tiles_touched, total);
+    const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
+    const uint32_t un = (uint32_t)n;
+
+    // (1) stable sort of the Gaussians by depth bits (positive floats order as unsigned ints)
+    hipLaunchKernelGGL(k_depth_keys, dim3(nblocks_for(n, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
+                       means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1]);
     CUGS_LAUNCH_CHECK();
+    int rc;
+    if ((rc = radix_pass<true>(ws.dkey[1], nullptr, un, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], st))) return rc;
+    if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], st))) return rc;
+    if ((rc = radix_pass<false>(ws.dkey[1], ws.dval[1], un, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], st))) return rc;
+    if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], st))) return rc;
+
+    // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
+    const uint32_t nfill = nblocks_for(n, FILL_CHUNK);
+    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], tiles_touched,
+                       ws.blocksum);
+    CUGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(CUGS_BLOCK), 0, st, ws.blocksum, nfill, ws.total);
+    CUGS_LAUNCH_CHECK();
+
     unsigned long long host_total = 0;
-    CUGS_RETURN_IF_HIP(hipMemcpyAsync(&host_total, total, sizeof(host_total), hipMemcpyDeviceToHost, st));
+    CUGS_RETURN_IF_HIP(hipMemcpyAsync(&host_total, ws.total, sizeof(host_total), hipMemcpyDeviceToHost, st));
     CUGS_RETURN_IF_HIP(hipStreamSynchronize(st));
     if (host_total > 2147483647ull) return CUGS_EOVERFLOW;   // the reference indexes pairs with int
     *total_pairs_host = (int64_t)host_total;
@@ -445,8 +467,9 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const int32_t* tiles_touched, vo
 extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* means_2d,
                                const float* depths, const int32_t* radii,
                                const int32_t* tiles_touched, int width, int height, void* workspace,
-                               size_t workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
-                               int32_t* tile_ranges, void* stream) {
+                               size_t workspace_bytes, void* pair_workspace, size_t pair_workspace_bytes,
+                               uint64_t* keys_sorted, int32_t* values_sorted, int32_t* tile_ranges,
+                               void* stream) {
     if (n < 0 || total_pairs < 0 || width < 0 || height < 0 || !tile_ranges) return CUGS_EINVAL;
     if (n > 2147483647ll || total_pairs > 2147483647ll) return CUGS_EOVERFLOW;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -455,49 +478,34 @@ extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* mean
     if (tiles > 0)   // untouched tiles stay {0,0} (sorting.cu:216)
         CUGS_RETURN_IF_HIP(hipMemsetAsync(tile_ranges, 0, sizeof(int32_t) * 2 * (size_t)tiles, st));
     if (n == 0 || total_pairs == 0 || tiles == 0) return 0;      // sorting.cu:133-139,154-160
-    if (!means_2d || !depths || !radii || !tiles_touched || !values_sorted || !workspace) return CUGS_EINVAL;
-    SortWs ws = carve(workspace, n, total_pairs);
-    if (workspace_bytes < ws.bytes) return CUGS_EWORKSPACE;
+    if (!means_2d || !depths || !radii || !tiles_touched || !values_sorted || !workspace || !pair_workspace)
+        return CUGS_EINVAL;
+    SortWsN ws = carve_n(workspace, n);
+    SortWsP wp = carve_p(pair_workspace, total_pairs);
+    if (workspace_bytes < ws.bytes || pair_workspace_bytes < wp.bytes) return CUGS_EWORKSPACE;
 
-    // (1) stable sort of the Gaussians by depth bits (positive floats order as unsigned ints)
     const uint32_t un = (uint32_t)n, up = (uint32_t)total_pairs;
-    uint32_t* zero_pairs = reinterpret_cast<uint32_t*>(ws.total) + 4;     // inside the first 256-byte slot
+    uint32_t* zero_pairs = reinterpret_cast<uint32_t*>(ws.total) + 4;
     CUGS_RETURN_IF_HIP(hipMemsetAsync(zero_pairs, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_depth_keys, dim3(nblocks_for(n, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
-                       means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1]);
-    CUGS_LAUNCH_CHECK();
-    int rc;
-    if ((rc = radix_pass<true>(ws.dkey[1], nullptr, un, 0, 8, ws, ws.dkey[0], ws.dval[0], st))) return rc;
-    if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 8, 8, ws, ws.dkey[1], ws.dval[1], st))) return rc;
-    if ((rc = radix_pass<false>(ws.dkey[1], ws.dval[1], un, 16, 8, ws, ws.dkey[0], ws.dval[0], st))) return rc;
-    if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 24, 8, ws, ws.dkey[1], ws.dval[1], st))) return rc;
-    const uint32_t* order = ws.dval[1];
-
-    // (2) pairs in depth order
+    const uint32_t* order = ws.dval[1];                 // left there by cugs_sort_count_pairs
     const uint32_t nfill = nblocks_for(n, FILL_CHUNK);
-    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, order, tiles_touched,
-                       ws.blocksum);
-    CUGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(CUGS_BLOCK), 0, st, ws.blocksum, nfill);
-    CUGS_LAUNCH_CHECK();
 
-    // (3) stable sort by tile id: choose the buffers so that the last pass lands in values_sorted
+    // (2b) pairs in depth order; (3) stable sort by tile id, last pass landing in values_sorted
     const int bits = tile_bits(tiles);
     const int npass = (bits + 7) / 8;
     const int per = (bits + npass - 1) / npass;
     uint32_t* vals_final = reinterpret_cast<uint32_t*>(values_sorted);
-    // pass p reads (tk[p&1], tv_in) and writes (tk[(p+1)&1], tv_out)
-    uint32_t* tk[2] = {ws.ptile[0], ws.ptile[1]};
-    uint32_t* tv[2] = {ws.pidx[0], ws.pidx[1]};
+    uint32_t* tk[2] = {wp.ptile[0], wp.ptile[1]};
+    uint32_t* tv[2] = {wp.pidx[0], wp.pidx[1]};
     hipLaunchKernelGGL(k_fill_pairs, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, up, order, tiles_touched,
                        means_2d, radii, width, height, ntx, nty, ws.blocksum, tk[0], tv[0], zero_pairs);
     CUGS_LAUNCH_CHECK();
-    int cur = 0;
+    int cur = 0, rc;
     for (int p = 0; p < npass; ++p) {
         const int shift = p * per;
         const int b = (bits - shift) < per ? (bits - shift) : per;
         uint32_t* vout = (p == npass - 1) ? vals_final : tv[cur ^ 1];
-        if ((rc = radix_pass<false>(tk[cur], tv[cur], up, shift, b, ws, tk[cur ^ 1], vout, st))) return rc;
+        if ((rc = radix_pass<false>(tk[cur], tv[cur], up, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, st))) return rc;
         cur ^= 1;
     }
     hipLaunchKernelGGL(k_tile_ranges, dim3(nblocks_for(total_pairs, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st,

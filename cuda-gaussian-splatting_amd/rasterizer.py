@@ -45,16 +45,18 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous().to(torch.float32)
 
 
-_workspaces: Dict[torch.device, torch.Tensor] = {}
+_workspaces: Dict[tuple, torch.Tensor] = {}
 
 
-def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+def _workspace(device: torch.device, nbytes: int, kind: str = "n") -> torch.Tensor:
     """Caller-owned scratch for the sort: grown on demand, reused across calls (the reference
-    allocates CUB temp storage on every call, sorting.cu:198-200)."""
-    ws = _workspaces.get(device)
+    allocates CUB temp storage on every call, sorting.cu:198-200).  `kind`: "n" = the N-level buffer
+    that carries state from cugs_sort_count_pairs to cugs_sort_pairs, "p" = the pair-level buffer."""
+    key = (device, kind)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 
@@ -149,19 +151,20 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
     st = _stream(dev)
     total = C.c_int64(0)
     tiles_c = tiles_touched.contiguous().to(torch.int32)
+    means_c, depths_c, radii_c = means_2d.contiguous(), depths.contiguous(), radii.contiguous()
+    ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n")
     if n > 0:
-        ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n, 0, img_w, img_h))
-        check(lib.cugs_sort_count_pairs(n, _ptr(tiles_c), _ptr(ws), ws.numel(), C.byref(total), st),
-              "cugs_sort_count_pairs")
+        check(lib.cugs_sort_count_pairs(n, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w),
+                                        int(img_h), _ptr(ws), ws.numel(), C.byref(total), st), "cugs_sort_count_pairs")
     p = int(total.value)
     keys = torch.empty((p if want_keys else 0,), dtype=torch.int64, device=dev)
     vals = torch.empty((p,), **i32)
     if num_tiles > 0:
-        ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n, p, img_w, img_h))
-        check(lib.cugs_sort_pairs(n, p, _ptr(means_2d.contiguous()), _ptr(depths.contiguous()),
-                                  _ptr(radii.contiguous()), _ptr(tiles_c), int(img_w), int(img_h), _ptr(ws),
-                                  ws.numel(), _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals),
-                                  _ptr(tile_ranges), st), "cugs_sort_pairs")
+        wp = _workspace(dev, lib.cugs_sort_pair_workspace_bytes(p), "p")
+        check(lib.cugs_sort_pairs(n, p, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w),
+                                  int(img_h), _ptr(ws), ws.numel(), _ptr(wp), wp.numel(),
+                                  _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals), _ptr(tile_ranges), st),
+              "cugs_sort_pairs")
     return SortingOutput(keys, vals, tile_ranges, p)
 
 

@@ -85,21 +85,29 @@ int cugs_pack_projected(int64_t n, const float* means_2d, const float* cov_2d_in
 /* ---- a5: sort_gaussians (sorting.cu:115-227) ----------------------------------------
  * Replaces the cumsum + .item() (sorting.cu:145-146), k_fill_sort_pairs (:30-72),
  * cub::DeviceRadixSort::SortPairs (:191-210; contract: ascending, stable, full 64-bit key)
- * and k_compute_tile_ranges (:82-109).  The workspace query replaces CUB's two-call
- * temp-storage idiom (:191-198).  max_pairs bounds total_pairs. */
-size_t cugs_sort_workspace_bytes(int64_t n, int64_t max_pairs, int width, int height);
+ * and k_compute_tile_ranges (:82-109).  The two workspace queries replace CUB's two-call
+ * temp-storage idiom (:191-198): `workspace` (N-level, cugs_sort_workspace_bytes(n)) carries
+ * state from cugs_sort_count_pairs to cugs_sort_pairs and must be the same buffer in both calls,
+ * with the same per-Gaussian inputs; `pair_workspace` (cugs_sort_pair_workspace_bytes(P)) can
+ * only be sized after the count. */
+size_t cugs_sort_workspace_bytes(int64_t n);
+size_t cugs_sort_pair_workspace_bytes(int64_t total_pairs);
 
-/* total_pairs = sum(tiles_touched).  BLOCKS until the value is on the host (the reference's
- * one forced sync).  `workspace` needs cugs_sort_workspace_bytes(n, 0, w, h) bytes. */
-int cugs_sort_count_pairs(int64_t n, const int32_t* tiles_touched, void* workspace,
-                          size_t workspace_bytes, int64_t* total_pairs_host, void* stream);
+/* total_pairs = sum(tiles_touched).  BLOCKS until the value is on the host (the reference's one
+ * forced sync) - after having queued all the work that does not depend on it (depth ordering of
+ * the Gaussians), so the device is busy while the host waits. */
+int cugs_sort_count_pairs(int64_t n, const float* means_2d, const float* depths,
+                          const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                          void* workspace, size_t workspace_bytes, int64_t* total_pairs_host,
+                          void* stream);
 
 /* keys_sorted [P] u64 (tile_id<<32 | depth bits; may be NULL), values_sorted [P] i32,
  * tile_ranges [tiles,2] i32 ({0,0} for untouched tiles, sorting.cu:216). */
 int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* means_2d, const float* depths,
                     const int32_t* radii, const int32_t* tiles_touched, int width, int height,
-                    void* workspace, size_t workspace_bytes, uint64_t* keys_sorted,
-                    int32_t* values_sorted, int32_t* tile_ranges, void* stream);
+                    void* workspace, size_t workspace_bytes, void* pair_workspace,
+                    size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                    int32_t* tile_ranges, void* stream);
 
 /* ---- a6: rasterize_forward (forward.cu:180-240, kernel :48-174) ---------------------
  * out_color [H,W,3], out_final_T [H,W], out_n_contrib [H,W] i32.  `packed` may be NULL

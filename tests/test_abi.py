@@ -50,9 +50,9 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.cugs_evaluate_sh(1, 0, 4, null, null, null, null) == 0
     assert lib.cugs_fused_adam(null, null, null, null, 0, 0.1, 0.9, 0.999, 1e-15, 1.0, 1.0, null) == 0
     assert lib.cugs_fused_adam(null, null, null, null, 8, 0.1, 0.9, 0.999, 1e-15, 1.0, 1.0, null) == -1
-    assert lib.cugs_sort_workspace_bytes(-1, 0, 16, 16) == 0
-    small, big = lib.cugs_sort_workspace_bytes(1000, 0, 64, 64), lib.cugs_sort_workspace_bytes(1000, 5000, 64, 64)
-    assert 0 < small < big
+    assert lib.cugs_sort_workspace_bytes(-1) == 0 and lib.cugs_sort_pair_workspace_bytes(-1) == 0
+    assert 0 < lib.cugs_sort_workspace_bytes(1000) < lib.cugs_sort_workspace_bytes(100000)
+    assert 0 < lib.cugs_sort_pair_workspace_bytes(10) < lib.cugs_sort_pair_workspace_bytes(5000)
     # misaligned accumulator -> CUGS_EALIGN
     bg = (C.c_float * 3)(0, 0, 0)
     assert lib.cugs_rasterize_backward(16, 16, bg, null, null, null, null, null, null, null, null, null, null, 4,

@@ -31,10 +31,10 @@ def test_cpp_adapter_matches_python_host(pkg, dev, tmp_path):
     assert camvec.size == 26
     camvec.tofile(tmp_path / "camera.bin")
 
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUGS_ADAPTER_TRACE="1")
     res = subprocess.run([DRIVER, str(tmp_path), str(n), "16", str(w), str(h)], capture_output=True, text=True,
                          timeout=300, env=env)
-    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.returncode == 0, f"rc={res.returncode} stdout={res.stdout!r} stderr={res.stderr!r}"
     assert "torch_check=1" in res.stdout                     # TORCH_CHECK -> c10::Error on a CPU tensor
 
     model = pkg.scene.to_model(arrays, dev)

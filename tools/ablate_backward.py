@@ -55,3 +55,5 @@ st = acc[wl.n].cpu().numpy()
 tiles = ((wl.width + 15) // 16) * ((wl.height + 15) // 16)
 print("rc", rc, "wave-steps %.3g  contributing %.3g (%.0f%%)  lanes/contributing step %.1f  wave-batches walked %.3g of %.3g  records cull-tested %.3g  (pairs x4 waves = %.3g)"
       % (st[0], st[1], 100 * st[1] / max(st[0], 1), st[2] / max(st[1], 1), st[3], st[5], st[4], 4.0 * out.total_pairs))
+print("4x4 sub-blocks with a contributing pixel per contributing step: %.2f of 4;  not-finished lanes per contributing step: %.1f of 64"
+      % (st[6] / max(st[1], 1), st[7] / max(st[1], 1)))
