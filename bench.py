@@ -192,7 +192,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run
+    if launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -228,7 +229,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if launched:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
@@ -241,7 +242,7 @@ def main():
         pairs, _, _ = step(events)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if launched:                                          # MAX over ranks
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -289,7 +290,7 @@ def main():
         if not args.no_parity and not forward_only and n_gpus == 1:
             out["parity"] = parity_probe(pkg, orc, dev)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

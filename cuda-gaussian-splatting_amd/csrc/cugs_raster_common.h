@@ -111,91 +111,95 @@ __device__ __forceinline__ ActiveRect active_rect(unsigned long long active, flo
     return ActiveRect{quad_cx + (float)x0, quad_cy + (float)y0, (float)(x1 - x0), (float)(y1 - y0)};
 }
 
-// forward.cu:124-141 / backward.cu:123-137 for one pixel.  FMA placement contract:
+// forward.cu:124-141 / backward.cu:123-137 for one pixel, written so that every per-lane decision
+// stays in VECTOR registers.  (hipcc keeps a C++ `bool` that differs per lane as a 64-bit lane mask in
+// scalar registers and turns `a && b`, `done |= x` into s_and/s_or_b64; a CU has ONE scalar unit for its
+// four SIMDs, and the ~45 scalar instructions per step this produced cost more issue time than the
+// ~110 vector ones.)  The pixel's "still open" state is a float flag (1 or 0) multiplied into the
+// opacity, and skips become alpha = 0, which makes every later product exactly zero.
+//
+// Decisions are the oracle's, bit for bit.  FMA placement contract:
 //   u = fma(a,dx,b*dy); v = fma(b,dx,c*dy); q = fma(dx,u,dy*v); power = -0.5f*q.
-// power < -5.6 can be dropped before the exponential: exp(-5.6)(1+2^-22) = 0.0036979 and
-// opacity <= 1, so alpha < 1/255 = 0.0039216 is certain (the oracle reaches the same skip
-// through its alpha test).  Returns false when the Gaussian is skipped at this pixel.
-struct PixelEval { float dx, dy, power, e, alpha; };
-__device__ __forceinline__ bool pixel_alpha(float pxf, float pyf, float mx, float my, float a, float b,
-                                            float c, float o, PixelEval& r) {
+//   * power > 0 -> skipped: the exponent is replaced by -6;
+//   * power < -6 is clamped to -6: exp(-6)(1+2^-22) = 0.00248 and opacity <= 1, so alpha < 1/255 =
+//     0.00392 is certain - the oracle reaches the same skip through its alpha test (and its exp flushes
+//     below -87.3); inside [-6, 0] cugs_expf_core IS cugs_expf;
+//   * open == 0 -> alpha = 0 < 1/255 -> skipped.
+// Returns alpha if the Gaussian passes at this pixel, else exactly 0.
+struct PixelEval { float dx, dy, gx, gy, e; };
+__device__ __forceinline__ float pixel_alpha(float pxf, float pyf, float mx, float my, float a, float b,
+                                             float c, float o, float open, PixelEval& r) {
     r.dx = pxf - mx;
     r.dy = pyf - my;
-    const float u = fmaf(a, r.dx, b * r.dy);
-    const float v = fmaf(b, r.dx, c * r.dy);
-    const float q = fmaf(r.dx, u, r.dy * v);
-    r.power = -0.5f * q;
-    if (r.power > 0.0f || r.power < -5.6f) return false;
-    r.e = cugs_expf_core(r.power);
-    r.alpha = fminf(o * r.e, 0.99f);
-    return !(r.alpha < (1.0f / 255.0f));
+    r.gx = fmaf(a, r.dx, b * r.dy);
+    r.gy = fmaf(b, r.dx, c * r.dy);
+    const float power = -0.5f * fmaf(r.dx, r.gx, r.dy * r.gy);
+    float pw = fmaxf(power, -6.0f);
+    pw = (power > 0.0f) ? -6.0f : pw;
+    r.e = cugs_expf_core(pw);
+    const float alpha = fminf((o * open) * r.e, 0.99f);       // o * 1.0f is exact
+    return (alpha < (1.0f / 255.0f)) ? 0.0f : alpha;
 }
 
 // ---------------------------------------------------------------------------------------
 // reduce9: sums NINE per-lane values across the 64 lanes of a wave and leaves each total in a
-// different lane (27 VALU-class operations instead of 9 x 6 DPP adds + a 9-way select).
+// different lane (33 VALU-class operations instead of 9 x 6 DPP adds + a 9-way select).
 //
-// Idea ("transpose-reduce"): at every halving step two partner lanes exchange the half of the
-// values they will not keep, so the number of live values per lane halves as the number of lanes
-// sharing a sum doubles.  gfx950 has single instructions for the two cross-row exchanges:
-//   v_permlane32_swap D,S : swaps D[32..63] with S[0..31]         -> D+S = {sum32(D) | sum32(S)}
-//   v_permlane16_swap D,S : swaps D.row1<->S.row0, D.row3<->S.row2 -> D+S = rows {D, S, D, S}
-// and the in-row steps use DPP row_mirror / row_half_mirror / quad_perm with a select.
-// All 64 lanes must be active (EXEC full): callers run it in wave-uniform control flow with
-// zeros in lanes that have nothing to add.
+// "Transpose-reduce": at every halving step two partner lanes exchange the half of the values they
+// will not keep (`keep = side ? b : a; give = side ? a : b; keep + dpp(give)`), so the number of live
+// values per lane halves as the number of lanes sharing a sum doubles.  Inside each 16-lane row the
+// partners / sides are
+//   row_mirror (i <-> 15-i, side = bit3), row_half_mirror (i <-> i^7, side = bit2),
+//   quad_perm[3,2,1,0] (i <-> i^3, side = bit1), quad_perm[1,0,3,2] (i <-> i^1, side = bit0)
+// (before each step both partners hold the same set of values: their higher side bits agree); live
+// values 9 -> 5 -> 3 -> 2 -> 1.  The four row totals of the single remaining value are then combined
+// with gfx950's v_permlane16_swap / v_permlane32_swap (x = t, y = t; swap; x + y), which measured
+// markedly cheaper than doing the two cross-row halvings first on nine values (8 swaps).
+// All 64 lanes must be active (EXEC full): callers run it in wave-uniform control flow with zeros in
+// lanes that have nothing to add.
 //
-// Result: after reduce9(v0..v8) the return value of lane L holds the wave total of slot
-// reduce9_slot(L) (or is meaningless when that is -1):
-//   row r = L >> 4, i = L & 15:  i == 0 -> {v0, v2, v1, v3}[r];  i == 8 -> {v4, v6, v5, v7}[r];
-//   i == 4 and r == 0 -> v8.
-// ---------------------------------------------------------------------------------------
+// Result: lane L (any row; i = L & 15) returns the WAVE total of slot reduce9_slot(L):
+//   i even: slot 4*bit1 + 2*bit2 + bit3  (i = 0,8,4,12,2,10,6,14 -> slots 0..7);  i == 1: slot 8;
+//   only row 0's lanes are designated to deliver.
+//
 // The swaps are issued through inline asm: with ROCm 7.2's hipcc the two results of
 // __builtin_amdgcn_permlane{16,32}_swap collapse into one register when both feed the same add
 // (observed: `v_permlane32_swap v2, v3 ; v_add_f32 v2, v2, v2`).  hipcc pads nothing inside an asm
 // statement, so the 2 wait states it otherwise inserts between a VALU write and a swap that reads
-// the register (s_nop 1) are part of the string; each stage's swaps share one block.
-typedef unsigned cugs_u2 __attribute__((ext_vector_type(2)));
+// the register (s_nop 1) are part of the string.
+// ---------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
+template <int CTRL>
+__device__ __forceinline__ float xchg_add(bool side, float a, float b) {
+    return (side ? b : a) + dpp_mov<CTRL>(side ? a : b);
+}
 
 __device__ __forceinline__ int reduce9_slot(int lane) {
-    const int r = lane >> 4, i = lane & 15;
-    if (i == 0) return (r == 0) ? 0 : (r == 1) ? 2 : (r == 2) ? 1 : 3;
-    if (i == 8) return (r == 0) ? 4 : (r == 1) ? 6 : (r == 2) ? 5 : 7;
-    if (i == 4 && r == 0) return 8;
-    return -1;
+    const int li = lane & 15;
+    if (lane >= 16) return -1;
+    if (li == 1) return 8;
+    if (li & 1) return -1;
+    return ((li >> 1) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 3) & 1);
 }
 
 __device__ __forceinline__ float reduce9(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
                                          float v7, float v8, int lane) {
-    // halves: lanes 0..31 keep the first of each pair, lanes 32..63 the second
-    float z8 = 0.0f;
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane32_swap_b32 %0, %1\n\t"
-                 "v_permlane32_swap_b32 %2, %3\n\t"
-                 "v_permlane32_swap_b32 %4, %5\n\t"
-                 "v_permlane32_swap_b32 %6, %7\n\t"
-                 "v_permlane32_swap_b32 %8, %9"
-                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(z8));
-    float x0 = v0 + v1, x1 = v2 + v3, x2 = v4 + v5, x3 = v6 + v7, x4 = v8 + z8;
-    // rows: even rows keep the first, odd rows the second  -> rows {v0,v2,v1,v3}, {v4,v6,v5,v7}, {v8,0,0,0}
-    float z4 = 0.0f;
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane16_swap_b32 %0, %1\n\t"
-                 "v_permlane16_swap_b32 %2, %3\n\t"
-                 "v_permlane16_swap_b32 %4, %5"
-                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(z4));
-    const float y0 = x0 + x1, y1 = x2 + x3, y2 = x4 + z4;
-    // in-row: i <-> 15-i ; lanes with bit3 = 0 keep y0, bit3 = 1 keep y1 ; y2 plain
-    const bool hi8 = (lane & 8) != 0;
-    const float z0 = (hi8 ? y1 : y0) + dpp_mov<0x140>(hi8 ? y0 : y1);
-    const float z1 = y2 + dpp_mov<0x140>(y2);
-    // i <-> i^7 ; bit2 = 0 keeps z0, bit2 = 1 keeps z1
-    const bool hi4 = (lane & 4) != 0;
-    float w = (hi4 ? z1 : z0) + dpp_mov<0x141>(hi4 ? z0 : z1);
-    w += dpp_mov<0x1B>(w);      // quad_perm [3,2,1,0]
-    w += dpp_mov<0xB1>(w);      // quad_perm [1,0,3,2]
-    return w;
+    const bool s3 = (lane & 8) != 0, s2 = (lane & 4) != 0, s1 = (lane & 2) != 0, s0 = (lane & 1) != 0;
+    const float a0 = xchg_add<0x140>(s3, v0, v1), a1 = xchg_add<0x140>(s3, v2, v3);      // row_mirror
+    const float a2 = xchg_add<0x140>(s3, v4, v5), a3 = xchg_add<0x140>(s3, v6, v7);
+    const float a4 = v8 + dpp_mov<0x140>(v8);
+    const float b0 = xchg_add<0x141>(s2, a0, a1), b1 = xchg_add<0x141>(s2, a2, a3);      // row_half_mirror
+    const float b2 = a4 + dpp_mov<0x141>(a4);
+    const float c0 = xchg_add<0x1B>(s1, b0, b1);                                         // quad_perm [3,2,1,0]
+    const float c1 = b2 + dpp_mov<0x1B>(b2);
+    float x = xchg_add<0xB1>(s0, c0, c1);                                                // quad_perm [1,0,3,2]
+    float y = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));         // rows 0+1, 2+3
+    x += y;
+    y = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));         // halves
+    return x + y;
 }

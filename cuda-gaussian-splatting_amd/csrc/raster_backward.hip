@@ -66,11 +66,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     float S0 = T * geo.bg0, S1 = T * geo.bg1, S2 = T * geo.bg2;      // backward.cu:83-87
     int found = 0;
     // A pixel with n_contrib == 0 stops at its first passing Gaussian without contributing
-    // (backward.cu:141-145), so it can start out finished.
-    bool done = !inside || max_contrib <= 0;
-    bool wave_done = (__ballot(!done) == 0ull);
+    // (backward.cu:141-145), so it can start out finished.  `open`: 1 while the pixel is still walking.
+    float open = (inside && max_contrib > 0) ? 1.0f : 0.0f;
+    bool wave_done = (__ballot(open != 0.0f) == 0ull);
     const int my_slot = reduce9_slot(lane);
-    unsigned st_steps = 0, st_contrib = 0, st_lanes = 0, st_batches = 0, st_tested = 0, st_sub = 0, st_open = 0;   // ABL == 4 only
+    unsigned st_steps = 0, st_contrib = 0, st_lanes = 0, st_batches = 0, st_tested = 0, st_open = 0;   // ABL == 4 only
 
     for (int batch = num_batches - 1; batch >= 0; --batch) {
         if (lane == 0) s_wave_done[wave] = wave_done ? 1 : 0;
@@ -86,86 +86,64 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
             const int nsub = (batch_count + CUGS_WAVE - 1) / CUGS_WAVE;
             for (int sub = nsub - 1; sub >= 0 && !wave_done; --sub) {
                 const int j = sub * CUGS_WAVE + lane;
-                const ActiveRect ar = active_rect(__ballot(!done), qx0, qy0);   // !wave_done => non-empty
+                const ActiveRect ar = active_rect(__ballot(open != 0.0f), qx0, qy0);   // !wave_done => non-empty
                 bool hit = false;
                 if (j < batch_count)
                     hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1],
                                          s_rec[j * CUGS_REC_F4 + 2], ar.x0, ar.y0, ar.wx, ar.wy);
                 unsigned long long mask = __ballot(hit);
                 if (ABL == 4) st_tested += min(CUGS_WAVE, batch_count - sub * CUGS_WAVE);
-                if (mask == 0ull) continue;
-                // Software pipeline: the next record's three 16-byte LDS reads are in flight while the
-                // current one is evaluated.  Records are walked back to front (highest bit first).
-                int bit = 63 - __builtin_clzll(mask);
-                mask &= ~(1ull << bit);
-                const float4* rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
-                float4 n0 = rp[0], n1 = rp[1], n2 = rp[2];
-                while (true) {
+                while (mask != 0ull) {                                     // back to front: highest bit first
                     if (ABL == 4) ++st_steps;
-                    const float4 g0 = n0, g1 = n1, g2 = n2;
-                    const bool more = (mask != 0ull);
-                    if (more) {
-                        bit = 63 - __builtin_clzll(mask);
-                        mask &= ~(1ull << bit);
-                        rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
-                        n0 = rp[0]; n1 = rp[1]; n2 = rp[2];
-                    }
+                    const int bit = 63 - __builtin_clzll(mask);
+                    mask &= ~(1ull << bit);
+                    const float4* rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
+                    const float4 g0 = rp[0], g1 = rp[1], g2 = rp[2];
                     const float a = g0.z, b = g0.w, c = g1.x, o = g2.x;
 
-                    // ---- decisions: exactly pixel_alpha() + the contributor count (backward.cu:123-145),
-                    // written branch-free; a lane that is done or skips the Gaussian evaluates harmless values
-                    const float dx = pxf - g0.x, dy = pyf - g0.y;
-                    const float gx = fmaf(a, dx, b * dy), gy = fmaf(b, dx, c * dy);
-                    const float power = -0.5f * fmaf(dx, gx, dy * gy);
-                    const bool in_range = (ABL != 3) && !(power > 0.0f) && !(power < -5.6f);
-                    const float e = cugs_expf_core(in_range ? power : 0.0f);
-                    const float alpha = fminf(o * e, 0.99f);
-                    const bool pass = !done && in_range && !(alpha < (1.0f / 255.0f));
-                    found += pass ? 1 : 0;
-                    const bool live = pass && (found <= max_contrib);
-                    done = done || (pass && !live);                       // count exceeded n_contrib: stop
+                    // ---- decisions (backward.cu:123-145), all in vector registers: see pixel_alpha()
+                    PixelEval e;
+                    const float alpha_p = (ABL == 3) ? 0.0f : pixel_alpha(pxf, pyf, g0.x, g0.y, a, b, c, o, open, e);
+                    found += (alpha_p != 0.0f) ? 1 : 0;                    // contributors counted from the END (Q1)
+                    const float al = (found <= max_contrib) ? alpha_p : 0.0f;
+                    open = (alpha_p != al) ? 0.0f : open;                  // passed, but beyond n_contrib: finished
 
-                    const unsigned long long live_mask = __ballot(live);
-                    if (live_mask != 0ull) {                              // wave-uniform
-                        if (ABL == 4) {
-                            ++st_contrib; st_lanes += __popcll(live_mask);
-                            // 4x4 sub-blocks of the 8x8 quad (lane = y*8+x) holding a contributing pixel
-                            const unsigned long long left = 0x0F0F0F0F0F0F0F0Full;
-                            st_sub += ((live_mask & left & 0xFFFFFFFFull) != 0) + ((live_mask & ~left & 0xFFFFFFFFull) != 0) +
-                                      ((live_mask & left & ~0xFFFFFFFFull) != 0) + ((live_mask & ~left & ~0xFFFFFFFFull) != 0);
-                            st_open += __popcll(__ballot(!done));
-                        }
-                        // ---- values (v_rcp_f32 + FMAs; dead lanes produce exact zeros through `al`, `dpw`)
-                        const float al = live ? alpha : 0.0f;
-                        const float rcp = __builtin_amdgcn_rcpf(fmaxf(1.0f - al, 1e-5f));
-                        T = live ? T * rcp : T;                           // T_before = T_after / (1 - alpha)
-                        const float weight = al * T;
-                        float v0 = dC0 * weight, v1 = dC1 * weight, v2 = dC2 * weight;
-                        float dL_dalpha = dC0 * fmaf(T, g1.y, -S0 * rcp);
-                        dL_dalpha = fmaf(dC1, fmaf(T, g1.z, -S1 * rcp), dL_dalpha);
-                        dL_dalpha = fmaf(dC2, fmaf(T, g1.w, -S2 * rcp), dL_dalpha);
-                        S0 = fmaf(weight, g1.y, S0);
-                        S1 = fmaf(weight, g1.z, S1);
-                        S2 = fmaf(weight, g1.w, S2);
-                        const bool open = live && !(o * e >= 0.99f);      // clamp gate (backward.cu:181-191)
-                        float v3 = open ? dL_dalpha * e : 0.0f;
-                        const float dpw = open ? dL_dalpha * al : 0.0f;   // dL/dpower
-                        float v4 = dpw * gx, v5 = dpw * gy;
-                        const float hdp = -0.5f * dpw;
-                        float v6 = hdp * dx * dx, v7 = -dpw * dx * dy, v8 = hdp * dy * dy;
-                        if (ABL == 1) {
-                            asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8));
-                        } else {
-                            const float total = reduce9(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
-                            if (ABL == 2) {
-                                asm volatile("" ::"v"(total));
-                            } else if (my_slot >= 0) {
-                                atomicAdd(&grad_accum[(int64_t)__float_as_int(g2.z) * CUGS_GRAD_STRIDE + my_slot], total);
-                            }
+                    // ---- values (v_rcp_f32 + FMAs); al == 0 makes every sum below exactly zero
+                    const bool live = (al != 0.0f);
+                    const float rcp = __builtin_amdgcn_rcpf(fmaxf(1.0f - al, 1e-5f));
+                    T = live ? T * rcp : T;                                // T_before = T_after / (1 - alpha)
+                    const float weight = al * T;
+                    float v0 = dC0 * weight, v1 = dC1 * weight, v2 = dC2 * weight;
+                    float dL_dalpha = dC0 * fmaf(T, g1.y, -S0 * rcp);
+                    dL_dalpha = fmaf(dC1, fmaf(T, g1.z, -S1 * rcp), dL_dalpha);
+                    dL_dalpha = fmaf(dC2, fmaf(T, g1.w, -S2 * rcp), dL_dalpha);
+                    S0 = fmaf(weight, g1.y, S0);
+                    S1 = fmaf(weight, g1.z, S1);
+                    S2 = fmaf(weight, g1.w, S2);
+                    // clamp gate (backward.cu:181-191): o e >= 0.99 zeroes dL/do and dL/dpower, dL/drgb still flows
+                    const float gate = (o * e.e >= 0.99f) ? 0.0f : dL_dalpha;
+                    float v3 = live ? gate * e.e : 0.0f;
+                    const float dpw = gate * al;                           // dL/dpower
+                    float v4 = dpw * e.gx, v5 = dpw * e.gy;
+                    const float hdp = -0.5f * dpw;
+                    float v6 = hdp * e.dx * e.dx, v7 = -dpw * e.dx * e.dy, v8 = hdp * e.dy * e.dy;
+                    if (ABL == 4) {
+                        const unsigned long long lm = __ballot(live);
+                        if (lm) { ++st_contrib; st_lanes += __popcll(lm); st_open += __popcll(__ballot(open != 0.0f)); }
+                    }
+                    // Every step reduces and adds (93% of steps contribute; an all-zero add is harmless and
+                    // cheaper than the scalar test-and-branch that would skip it).
+                    if (ABL == 1) {
+                        asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8));
+                    } else {
+                        const float total = reduce9(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
+                        if (ABL == 2) {
+                            asm volatile("" ::"v"(total));
+                        } else if (my_slot >= 0) {
+                            atomicAdd(&grad_accum[(int64_t)__float_as_int(g2.z) * CUGS_GRAD_STRIDE + my_slot], total);
                         }
                     }
-                    if (__ballot(!done) == 0ull) { wave_done = true; break; }
-                    if (!more) break;
+                    if (__ballot(open != 0.0f) == 0ull) { wave_done = true; break; }
                 }
             }
         }
@@ -175,7 +153,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         float* st = grad_accum + (int64_t)stats_row * CUGS_GRAD_STRIDE;
         atomicAdd(&st[0], (float)st_steps); atomicAdd(&st[1], (float)st_contrib); atomicAdd(&st[2], (float)st_lanes);
         atomicAdd(&st[3], (float)st_batches); atomicAdd(&st[4], (float)st_tested); atomicAdd(&st[5], (float)num_batches);
-        atomicAdd(&st[6], (float)st_sub); atomicAdd(&st[7], (float)st_open);
+        atomicAdd(&st[7], (float)st_open);
     }
 }
 

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
 
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     int count = 0;
-    bool done = !inside;
-    bool wave_done = (__ballot(!done) == 0ull);
+    float open = inside ? 1.0f : 0.0f;                  // 1 while the pixel still blends, 0 once T < 1/255
+    bool wave_done = (__ballot(open != 0.0f) == 0ull);
 
     for (int batch = 0; batch < num_batches; ++batch) {
         // whole-tile early exit (forward.cu:97-101), one flag per wave instead of an atomicMin
@@ -54,43 +54,28 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
             const int batch_count = min(CUGS_BLOCK, num_in_range - batch * CUGS_BLOCK);
             for (int sub = 0; sub * CUGS_WAVE < batch_count && !wave_done; ++sub) {
                 const int j = sub * CUGS_WAVE + lane;
-                const ActiveRect ar = active_rect(__ballot(!done), qx0, qy0);   // !wave_done => non-empty
+                const ActiveRect ar = active_rect(__ballot(open != 0.0f), qx0, qy0);   // !wave_done => non-empty
                 bool hit = false;
                 if (j < batch_count)
                     hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1],
                                          s_rec[j * CUGS_REC_F4 + 2], ar.x0, ar.y0, ar.wx, ar.wy);
                 unsigned long long mask = __ballot(hit);
-                if (mask == 0ull) continue;
-                // Software pipeline: the next record's LDS reads are in flight while this one is blended.
-                int bit = __builtin_ctzll(mask);                            // front to back
-                mask &= mask - 1ull;
-                const float4* rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
-                float4 n0 = rp[0], n1 = rp[1];
-                float no = rp[2].x;
-                while (true) {
-                    const float4 g0 = n0, g1 = n1;                          // wave-uniform address: broadcast
-                    const float o = no;
-                    const bool more = (mask != 0ull);
-                    if (more) {
-                        bit = __builtin_ctzll(mask);
-                        mask &= mask - 1ull;
-                        rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
-                        n0 = rp[0]; n1 = rp[1]; no = rp[2].x;
-                    }
-                    if (!done) {
-                        PixelEval e;
-                        if (pixel_alpha(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, o, e)) {
-                            const float weight = e.alpha * T;
-                            C0 = fmaf(weight, g1.y, C0);
-                            C1 = fmaf(weight, g1.z, C1);
-                            C2 = fmaf(weight, g1.w, C2);
-                            T *= (1.0f - e.alpha);
-                            ++count;
-                            if (T < (1.0f / 255.0f)) done = true;
-                        }
-                    }
-                    if (__ballot(!done) == 0ull) { wave_done = true; break; }
-                    if (!more) break;
+                while (mask != 0ull) {                                      // front to back
+                    const float4* rp = s_rec + (sub * CUGS_WAVE + __builtin_ctzll(mask)) * CUGS_REC_F4;
+                    mask &= mask - 1ull;
+                    const float4 g0 = rp[0], g1 = rp[1];                    // wave-uniform address: broadcast
+                    const float o = rp[2].x;
+                    PixelEval e;
+                    const float al = pixel_alpha(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, o, open, e);
+                    // al == 0 (skipped or finished pixel) leaves C, T and count untouched exactly
+                    const float weight = al * T;
+                    C0 = fmaf(weight, g1.y, C0);
+                    C1 = fmaf(weight, g1.z, C1);
+                    C2 = fmaf(weight, g1.w, C2);
+                    T *= (1.0f - al);
+                    count += (al != 0.0f) ? 1 : 0;
+                    open = (T < (1.0f / 255.0f)) ? 0.0f : open;             // only a passing Gaussian can lower T
+                    if (__ballot(open != 0.0f) == 0ull) { wave_done = true; break; }
                 }
             }
         }
