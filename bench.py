@@ -74,7 +74,7 @@ def algorithmic_bytes(n, c, p, w, h):
     return b
 
 
-def timed_step(pkg, model, cam, settings, g, events, ws, do_allreduce, opt):
+def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt, all_centres=None):
     """One step with a HIP event before/after every stage (events live on torch's current stream,
     which is the stream every kernel of the C ABI is launched on)."""
     R = pkg.rasterizer
@@ -97,13 +97,19 @@ def timed_step(pkg, model, cam, settings, g, events, ws, do_allreduce, opt):
                               settings.background, n, packed=proj.packed, unpack=False)
     ev[4].record()
     d_means = torch.empty((n, 2), dtype=torch.float32, device=g.device)
+    compact = do_allreduce and exchange == "compact"
+    gated = torch.empty((n, 3), dtype=torch.float32, device=g.device) if compact else None
     pb = R.project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
                             model.opacities, model.sh_coeffs, proj.radii, cam, deg, settings.scale_modifier,
-                            grad_accum=rb.grad_accum, rgb_clamped=proj.rgb, dL_dmeans_2d_out=d_means)
+                            grad_accum=rb.grad_accum, rgb_clamped=proj.rgb, dL_dmeans_2d_out=d_means,
+                            dL_drgb_gated_out=gated, skip_sh_grad=compact)
     ev[5].record()
     grads = pkg.BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
                                pb.dL_dsh_coeffs, d_means)
-    if do_allreduce:
+    if compact:        # all-gather 12 B/G colour grads + all-reduce 44 B/G geometry grads, SH grads rebuilt locally
+        grads = pkg.parallel.exchange_gradients(grads, gated, model.positions, cam.camera_center(), deg,
+                                                int(model.sh_coeffs.shape[2]), all_cam_centers=all_centres)
+    elif do_allreduce:   # plain SUM all-reduce of all five tensors (236 B/G)
         pkg.parallel.allreduce_gradients(grads)
     if opt is not None:
         opt.apply_gradients(grads)
@@ -183,6 +189,9 @@ def main():
     ap.add_argument("--config", default="config3", choices=["config2", "config3", "config4"])
     ap.add_argument("--adam", action="store_true", help="include FusedAdam.step in the step (implied by config4)")
     ap.add_argument("--mu-s", type=float, default=None, help="override the log-scale mean (dense variant: -3.5)")
+    ap.add_argument("--exchange", default="compact", choices=["compact", "allreduce"],
+                    help="N>1 gradient exchange: compact = all-gather colour grads + all-reduce geometry grads "
+                         "(SH grads rebuilt locally); allreduce = SUM all-reduce of all five gradient tensors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=1 << 20,
@@ -220,12 +229,14 @@ def main():
     g = torch.from_numpy(g_host).to(dev)
     opt = pkg.FusedAdam(model) if use_adam else None
     c = pkg.sh_coeff_count(wl.sh_degree)
+    # every rank knows every view's camera in this benchmark: no device-to-host read of the gathered centres
+    all_centres = [pkg.scene.make_camera(wl.width, wl.height, view=r).camera_center().tolist() for r in range(world)]
 
     def step(events):
         if forward_only:
             out = pkg.render(model, cam, settings)
             return out.total_pairs, out, None
-        return timed_step(pkg, model, cam, settings, g, events, None, world > 1, opt)
+        return timed_step(pkg, model, cam, settings, g, events, args.exchange, world > 1, opt, all_centres)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -279,7 +290,7 @@ def main():
             "config": {"workload": wl.name + (" fwd only" if forward_only else " fwd+bwd") + (" +adam" if use_adam else ""),
                        "n_gaussians": wl.n, "width": wl.width, "height": wl.height, "sh_degree": wl.sh_degree,
                        "pairs": int(pairs), "mu_s": wl.mu_s, "views_per_step": n_gpus,
-                       "parallelism": f"dp{n_gpus}-views" + ("+rccl-allreduce" if n_gpus > 1 else "")},
+                       "parallelism": f"dp{n_gpus}-views" + (f"+rccl-{args.exchange}" if n_gpus > 1 else "")},
             "roofline": roofline, "frame_roofline": frame,
             "stages_ms": {k: round(v, 4) for k, v in stages_ms.items()},
         }

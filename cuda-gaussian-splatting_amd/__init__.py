@@ -14,7 +14,7 @@ from .types import (BackwardOutput, CameraInfo, CameraIntrinsics, ForwardOutput,
                     RenderSettings, SortingOutput, K_MAX_SH_DEGREE, K_TILE_SIZE, sh_coeff_count)
 from .rasterizer import (evaluate_sh_backward_cuda, evaluate_sh_cuda, project_backward,  # noqa: F401
                          project_gaussians, rasterize_backward, rasterize_forward, render, render_backward,
-                         sort_gaussians)
+                         sh_backward_views, sort_gaussians)
 from .fused_adam import (AdamConfig, FusedAdam, ParamGroup, PositionLRConfig,  # noqa: F401
                          active_sh_degree_for_step, lr_defaults, position_lr)
 from . import parallel, scene  # noqa: F401

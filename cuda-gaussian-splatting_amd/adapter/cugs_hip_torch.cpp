@@ -182,7 +182,8 @@ ProjectionBackwardOutput project_backward_impl(const torch::Tensor* accum, const
                                 accum ? ptr<float>(*accum) : nullptr, ptr<float>(cm), ptr<float>(cc), ptr<float>(cr),
                                 ptr<float>(co), ptr<float>(o.dL_dpositions), ptr<float>(o.dL_drotations),
                                 ptr<float>(o.dL_dscales), ptr<float>(o.dL_dopacities), ptr<float>(o.dL_dsh_coeffs),
-                                d_means_out ? ptr<float>(*d_means_out) : nullptr, stream_of(positions)),
+                                d_means_out ? ptr<float>(*d_means_out) : nullptr, /*dL_drgb_gated_out=*/nullptr,
+                                stream_of(positions)),
           "cugs_project_backward");
     return o;
 }

@@ -173,6 +173,7 @@ struct PBPtrs {
     const float* grad_accum;
     const float* g_means; const float* g_cov; const float* g_rgb; const float* g_opa;
     float* d_pos; float* d_rot; float* d_scl; float* d_opa; float* d_sh; float* d_means_out;
+    float* d_rgb_gated_out;      // [n,3] gated colour gradient (for the data-parallel exchange); may be NULL
 };
 
 template <int C, bool ALIGNED>
@@ -218,19 +219,22 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
             if (gate_from_sh) open = raw_colour(s_sh + threadIdx.x * LROW + ch * C, Y, num_active) > 0.0f;
             else open = p.rgb_clamped[idx * 3 + ch] > 0.0f;
             gated[ch] = g_rgb[ch] * (open ? 1.0f : 0.0f);          // sh_backward.cu:99-100
+            if (p.d_rgb_gated_out) p.d_rgb_gated_out[idx * 3 + ch] = gated[ch];
         }
     }
     if (gate_from_sh) __syncthreads();                         // coefficients consumed; reuse the tile
 
-    if (live) {
-        float* row = s_sh + threadIdx.x * LROW;
+    if (p.d_sh) {                                              // kernel-uniform
+        if (live) {
+            float* row = s_sh + threadIdx.x * LROW;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
+            for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-            for (int k = 0; k < C; ++k) row[ch * C + k] = (k < num_active) ? gated[ch] * Y[k] : 0.0f;
+                for (int k = 0; k < C; ++k) row[ch * C + k] = (k < num_active) ? gated[ch] * Y[k] : 0.0f;
+        }
+        __syncthreads();
+        store_sh_rows<C, ALIGNED>(p.d_sh, base, count, s_sh);
     }
-    __syncthreads();
-    store_sh_rows<C, ALIGNED>(p.d_sh, base, count, s_sh);
     if (!live) return;
 
     // ---- geometry ----
@@ -348,7 +352,69 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_sh_backward_generic(int64_t n, i
     }
 }
 
+// ---- data-parallel SH gradient: sum over V views of gated_v (x) Y(dir_v), in view order ----------
+// dL_dsh = gated_rgb_grad (x) Y(direction) is an outer product, so V ranks exchange the 12 B/Gaussian
+// gated colour gradients (all-gather) instead of all-reducing the 12C B/Gaussian SH gradients; every
+// rank then rebuilds the identical sum with this kernel (fixed order: bit-reproducible across ranks).
+constexpr int MAX_VIEWS = 16;
+struct ViewCenters { float c[MAX_VIEWS][3]; int count; };
+
+template <int C, bool ALIGNED>
+__global__ __launch_bounds__(CUGS_BLOCK) void k_sh_backward_views(int64_t n, int degree,
+                                                                  const float* __restrict__ positions,
+                                                                  const float* __restrict__ gated,   // [V][n][3]
+                                                                  ViewCenters vc, float* __restrict__ dL_dsh) {
+    constexpr int LROW = ShTile<C>::LROW;
+    __shared__ float s_sh[CUGS_BLOCK * LROW];
+    const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
+    const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
+    const int64_t idx = base + threadIdx.x;
+    const int num_active = active_count(degree);
+    if (idx < n) {
+        const V3 pos{positions[idx * 3 + 0], positions[idx * 3 + 1], positions[idx * 3 + 2]};
+        float acc[3][C];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int k = 0; k < C; ++k) acc[ch][k] = 0.0f;
+        for (int v = 0; v < vc.count; ++v) {
+            CamArgs cam;                                        // only the centre is used by view_direction()
+            cam.cc[0] = vc.c[v][0]; cam.cc[1] = vc.c[v][1]; cam.cc[2] = vc.c[v][2];
+            float Y[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            sh_basis(degree, view_direction(pos, cam), Y);
+            const float* g = gated + ((int64_t)v * n + idx) * 3;
+            const float g0 = g[0], g1 = g[1], g2 = g[2];
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                if (k < num_active) {
+                    acc[0][k] += g0 * Y[k];
+                    acc[1][k] += g1 * Y[k];
+                    acc[2][k] += g2 * Y[k];
+                }
+            }
+        }
+        float* row = s_sh + threadIdx.x * LROW;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int k = 0; k < C; ++k) row[ch * C + k] = acc[ch][k];
+    }
+    __syncthreads();
+    store_sh_rows<C, ALIGNED>(dL_dsh, base, count, s_sh);
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + CUGS_BLOCK - 1) / CUGS_BLOCK); }
+
+template <int C>
+int launch_shv(int64_t n, int degree, const float* pos, const float* gated, const ViewCenters& vc, float* out,
+               bool aligned, hipStream_t st) {
+    if (aligned)
+        hipLaunchKernelGGL((k_sh_backward_views<C, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, pos, gated, vc, out);
+    else
+        hipLaunchKernelGGL((k_sh_backward_views<C, false>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, pos, gated, vc, out);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
 
 template <int C>
 int launch_pb(int64_t n, int degree, const CamArgs& cam, const PBPtrs& p, bool aligned, hipStream_t st) {
@@ -381,23 +447,24 @@ extern "C" int cugs_project_backward(int64_t n, int num_coeffs, int active_degre
                                      const float* dL_dcov_2d_inv, const float* dL_drgb,
                                      const float* dL_dopacity_act, float* dL_dpositions, float* dL_drotations,
                                      float* dL_dscales, float* dL_dopacities, float* dL_dsh_coeffs,
-                                     float* dL_dmeans_2d_out, void* stream) {
+                                     float* dL_dmeans_2d_out, float* dL_drgb_gated_out, void* stream) {
     if (n < 0 || !camera_host) return CUGS_EINVAL;
     if (active_degree < 0 || active_degree > 3) return CUGS_EINVAL;
     if ((active_degree + 1) * (active_degree + 1) > num_coeffs) return CUGS_EINVAL;
     if (num_coeffs != 1 && num_coeffs != 4 && num_coeffs != 9 && num_coeffs != 16) return CUGS_EINVAL;
     if (n == 0) return 0;
     if (!positions || !rotations || !scales || !opacities || !radii || !dL_dpositions || !dL_drotations ||
-        !dL_dscales || !dL_dopacities || !dL_dsh_coeffs)
+        !dL_dscales || !dL_dopacities)
         return CUGS_EINVAL;
+    if (!dL_dsh_coeffs && !dL_drgb_gated_out) return CUGS_EINVAL;   // one of the two colour-gradient outputs
     if (!rgb_clamped && !sh_coeffs) return CUGS_EINVAL;
     if (!grad_accum && (!dL_dmeans_2d || !dL_dcov_2d_inv || !dL_drgb || !dL_dopacity_act)) return CUGS_EINVAL;
     if (grad_accum && !cugs_aligned16(grad_accum)) return CUGS_EALIGN;
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
     PBPtrs p{positions, rotations, scales, opacities, sh_coeffs, radii, rgb_clamped, grad_accum,
              dL_dmeans_2d, dL_dcov_2d_inv, dL_drgb, dL_dopacity_act, dL_dpositions, dL_drotations,
-             dL_dscales, dL_dopacities, dL_dsh_coeffs, dL_dmeans_2d_out};
-    const bool aligned = cugs_aligned16(dL_dsh_coeffs) && cugs_aligned16(rotations) && cugs_aligned16(dL_drotations) &&
+             dL_dscales, dL_dopacities, dL_dsh_coeffs, dL_dmeans_2d_out, dL_drgb_gated_out};
+    const bool aligned = (!dL_dsh_coeffs || cugs_aligned16(dL_dsh_coeffs)) && cugs_aligned16(rotations) && cugs_aligned16(dL_drotations) &&
                          (rgb_clamped || cugs_aligned16(sh_coeffs));
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (num_coeffs) {
@@ -427,5 +494,27 @@ extern "C" int cugs_evaluate_sh_backward(int degree, int64_t n, int num_coeffs, 
                                num_coeffs, sh_coeffs, directions, dL_dcolor, dL_dsh);
             CUGS_LAUNCH_CHECK();
             return 0;
+    }
+}
+
+extern "C" int cugs_sh_backward_views(int degree, int64_t n, int num_coeffs, const float* positions,
+                                      int num_views, const float* gated_rgb_views,
+                                      const float* cam_centers_host, float* dL_dsh, void* stream) {
+    if (degree < 0 || degree > 3 || n < 0 || num_views < 1 || num_views > MAX_VIEWS) return CUGS_EINVAL;
+    if ((degree + 1) * (degree + 1) > num_coeffs) return CUGS_EINVAL;
+    if (num_coeffs != 1 && num_coeffs != 4 && num_coeffs != 9 && num_coeffs != 16) return CUGS_EINVAL;
+    if (n == 0) return 0;
+    if (!positions || !gated_rgb_views || !cam_centers_host || !dL_dsh) return CUGS_EINVAL;
+    ViewCenters vc;
+    vc.count = num_views;
+    for (int v = 0; v < MAX_VIEWS; ++v)
+        for (int k = 0; k < 3; ++k) vc.c[v][k] = v < num_views ? cam_centers_host[v * 3 + k] : 0.0f;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool aligned = cugs_aligned16(dL_dsh);
+    switch (num_coeffs) {
+        case 1: return launch_shv<1>(n, degree, positions, gated_rgb_views, vc, dL_dsh, aligned, st);
+        case 4: return launch_shv<4>(n, degree, positions, gated_rgb_views, vc, dL_dsh, aligned, st);
+        case 9: return launch_shv<9>(n, degree, positions, gated_rgb_views, vc, dL_dsh, aligned, st);
+        default: return launch_shv<16>(n, degree, positions, gated_rgb_views, vc, dL_dsh, aligned, st);
     }
 }

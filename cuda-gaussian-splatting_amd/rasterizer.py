@@ -221,7 +221,9 @@ def project_backward(dL_dmeans_2d: Optional[torch.Tensor], dL_dcov_2d_inv: Optio
                      opacities: torch.Tensor, sh_coeffs: torch.Tensor, radii: torch.Tensor,
                      camera: CameraInfo, active_sh_degree: int, scale_modifier: float = 1.0,
                      grad_accum: Optional[torch.Tensor] = None, rgb_clamped: Optional[torch.Tensor] = None,
-                     dL_dmeans_2d_out: Optional[torch.Tensor] = None) -> ProjectionBackwardOutput:
+                     dL_dmeans_2d_out: Optional[torch.Tensor] = None,
+                     dL_drgb_gated_out: Optional[torch.Tensor] = None,
+                     skip_sh_grad: bool = False) -> ProjectionBackwardOutput:
     _torch_check(positions.is_cuda, "positions must be on CUDA")
     n = int(positions.shape[0])
     dev = positions.device
@@ -229,7 +231,7 @@ def project_backward(dL_dmeans_2d: Optional[torch.Tensor], dL_dcov_2d_inv: Optio
     d_pos, d_rot = torch.empty((n, 3), **f), torch.empty((n, 4), **f)
     d_scl, d_opa = torch.empty((n, 3), **f), torch.empty((n, 1), **f)
     sh_c = _f32c(sh_coeffs)
-    d_sh = torch.empty_like(sh_c)
+    d_sh = None if skip_sh_grad else torch.empty_like(sh_c)      # skipped in the data-parallel exchange
     if n == 0:
         return ProjectionBackwardOutput(d_pos, d_rot, d_scl, d_opa, d_sh)
     pos_c, rot_c, scl_c, opa_c = map(_f32c, (positions, rotations, scales, opacities))
@@ -240,9 +242,27 @@ def project_backward(dL_dmeans_2d: Optional[torch.Tensor], dL_dcov_2d_inv: Optio
                                     _ptr(cont(rgb_clamped)), C.byref(cam), float(scale_modifier),
                                     _ptr(cont(grad_accum)), _ptr(cont(dL_dmeans_2d)), _ptr(cont(dL_dcov_2d_inv)),
                                     _ptr(cont(dL_drgb)), _ptr(cont(dL_dopacity_act)), _ptr(d_pos), _ptr(d_rot),
-                                    _ptr(d_scl), _ptr(d_opa), _ptr(d_sh), _ptr(dL_dmeans_2d_out), _stream(dev)),
+                                    _ptr(d_scl), _ptr(d_opa), _ptr(d_sh), _ptr(dL_dmeans_2d_out),
+                                    _ptr(dL_drgb_gated_out), _stream(dev)),
           "cugs_project_backward")
     return ProjectionBackwardOutput(d_pos, d_rot, d_scl, d_opa, d_sh)
+
+
+def sh_backward_views(degree: int, positions: torch.Tensor, gated_rgb_views: torch.Tensor,
+                      cam_centers, num_coeffs: int) -> torch.Tensor:
+    """Sum over views of gated_rgb[v] (x) Y(dir_v) (cugs_sh_backward_views): the SH gradient of a
+    multi-view batch from the all-gathered 12 B/Gaussian colour gradients.  gated_rgb_views [V,N,3]."""
+    _torch_check(positions.is_cuda and gated_rgb_views.is_cuda, "inputs must be on CUDA")
+    v, n = int(gated_rgb_views.shape[0]), int(positions.shape[0])
+    _torch_check(gated_rgb_views.shape == (v, n, 3), "gated_rgb_views must be [V, N, 3]")
+    pos_c, g_c = _f32c(positions), _f32c(gated_rgb_views)
+    out = torch.empty((n, 3, num_coeffs), dtype=torch.float32, device=positions.device)
+    if n == 0:
+        return out
+    cc = (C.c_float * (3 * v))(*[float(x) for c in cam_centers for x in c])
+    check(lib.cugs_sh_backward_views(int(degree), n, int(num_coeffs), _ptr(pos_c), v, _ptr(g_c), cc, _ptr(out),
+                                     _stream(positions.device)), "cugs_sh_backward_views")
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -278,7 +298,11 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings) -
 
 
 def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: GaussianModel,
-                    camera: CameraInfo, settings: RenderSettings) -> BackwardOutput:
+                    camera: CameraInfo, settings: RenderSettings,
+                    dL_drgb_gated_out: Optional[torch.Tensor] = None) -> BackwardOutput:
+    """`dL_drgb_gated_out` ([N,3], optional, not in the reference): when given, the per-view SH gradient
+    is NOT materialised (dL_dsh_coeffs is None) and the gated colour gradient is written there instead,
+    for parallel.exchange_gradients() to rebuild the summed SH gradient after the all-gather."""
     _torch_check(dL_dcolor.is_cuda, "dL_dcolor must be on CUDA device")
     _torch_check(dL_dcolor.dim() == 3 and dL_dcolor.shape[2] == 3, "dL_dcolor must be [H, W, 3]")
     n = model.num_gaussians()
@@ -297,6 +321,7 @@ def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: Ga
     pb = project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
                           model.opacities, model.sh_coeffs, render_out.radii, camera, active_degree,
                           settings.scale_modifier, grad_accum=rb.grad_accum, rgb_clamped=render_out.rgb,
-                          dL_dmeans_2d_out=d_means_2d)
+                          dL_dmeans_2d_out=d_means_2d, dL_drgb_gated_out=dL_drgb_gated_out,
+                          skip_sh_grad=dL_drgb_gated_out is not None)
     return BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
                           pb.dL_dsh_coeffs, d_means_2d)

@@ -139,7 +139,9 @@ int cugs_rasterize_backward(int width, int height, const float background_host[3
  * NULL, from the four reference-layout arrays.  rgb_clamped (the forward's rgb) supplies
  * the ReLU gate (raw > 0 <=> clamped > 0, sh_backward.cu:92-100); when NULL the gate is
  * recomputed from sh_coeffs as the reference does.  dL_dmeans_2d_out ([n,2], may be NULL)
- * receives BackwardOutput::dL_dmeans_2d (rasterizer.cpp:184) when grad_accum is used. */
+ * receives BackwardOutput::dL_dmeans_2d (rasterizer.cpp:184) when grad_accum is used.
+ * dL_dsh_coeffs may be NULL when dL_drgb_gated_out ([n,3]: dL_drgb with the ReLU gate applied) is
+ * given instead: the data-parallel exchange (cugs_sh_backward_views) rebuilds the SH gradient from it. */
 int cugs_project_backward(int64_t n, int num_coeffs, int active_degree,
                           const float* positions, const float* rotations, const float* scales,
                           const float* opacities, const float* sh_coeffs, const int32_t* radii,
@@ -149,7 +151,16 @@ int cugs_project_backward(int64_t n, int num_coeffs, int active_degree,
                           const float* dL_drgb, const float* dL_dopacity_act,
                           float* dL_dpositions, float* dL_drotations, float* dL_dscales,
                           float* dL_dopacities, float* dL_dsh_coeffs, float* dL_dmeans_2d_out,
-                          void* stream);
+                          float* dL_drgb_gated_out, void* stream);
+
+/* ---- data-parallel extension (no counterpart in the single-GPU reference) ----------
+ * dL_dsh[i] = sum over views v of gated_rgb_views[v][i] (x) Y(normalize(positions[i] - centre_v)),
+ * accumulated in view order.  gated_rgb_views: [num_views][n][3] (the all-gather of every rank's
+ * dL_drgb_gated_out); cam_centers_host: [num_views][3]; num_views <= 16.  Equals the sum of the
+ * per-view evaluate_sh_backward_cuda results (sh_backward.cu:29-112) without moving them. */
+int cugs_sh_backward_views(int degree, int64_t n, int num_coeffs, const float* positions,
+                           int num_views, const float* gated_rgb_views,
+                           const float* cam_centers_host, float* dL_dsh, void* stream);
 
 /* ---- a11: FusedAdam (optimizer/fused_adam.cu:44-76,140-219) -------------------------
  * bc1 = 1/(1-beta1^t), bc2 = 1/(1-beta2^t) computed in double on the host, then float

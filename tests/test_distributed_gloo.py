@@ -27,8 +27,15 @@ def _worker(rank, world, port, q):
         pkg.parallel.wait_all(works)
         out = {f: getattr(grads, f).clone() for f in local}
         views = [pkg.parallel.view_for_rank(s, rank, world, 8) for s in range(4)]
+        # the collective half of the compact exchange on fresh per-rank data
+        g2 = pkg.BackwardOutput(mk(n, 3), mk(n, 4), mk(n, 3), mk(n, 1), None, mk(n, 2))
+        gated, centre = mk(n, 3), mk(3)
+        mine = dict(pos=g2.dL_dpositions.clone(), rot=g2.dL_drotations.clone(), gated=gated.clone(), centre=centre.clone())
+        flat, gviews, centres = pkg.parallel.collect_views(g2, gated, centre)
+        compact = dict(flat=flat.numpy(), views=gviews.numpy(), centres=centres.numpy(),
+                       **{k: v.numpy() for k, v in mine.items()})
         # numpy: pickled by value (torch tensors would travel as shared-memory handles)
-        q.put((rank, {k: v.numpy() for k, v in local.items()}, {k: v.numpy() for k, v in out.items()}, views))
+        q.put((rank, {k: v.numpy() for k, v in local.items()}, {k: v.numpy() for k, v in out.items()}, views, compact))
     finally:
         dist.destroy_process_group()
 
@@ -42,13 +49,19 @@ def test_allreduce_gradients_world2_gloo():
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    (_, l0, o0, v0), (_, l1, o1, v1) = res
+    (_, l0, o0, v0, c0), (_, l1, o1, v1, c1) = res
     for f in l0:
         if f == "dL_dmeans_2d":                       # per-view statistic: not reduced
             assert np.array_equal(o0[f], l0[f]) and np.array_equal(o1[f], l1[f])
         else:
             assert np.allclose(o0[f], l0[f] + l1[f]) and np.array_equal(o0[f], o1[f])
     assert set(v0).isdisjoint(v1) and v0 == [0, 2, 4, 6] and v1 == [1, 3, 5, 7]
+    # compact exchange: views stacked in RANK order on both ranks, geometry summed, layout pos|opa|scl|rot
+    for c in (c0, c1):
+        assert np.array_equal(c["views"][0], c0["gated"]) and np.array_equal(c["views"][1], c1["gated"])
+        assert np.array_equal(c["centres"][0], c0["centre"]) and np.array_equal(c["centres"][1], c1["centre"])
+        assert np.allclose(c["flat"][:, 0:3], c0["pos"] + c1["pos"]) and np.allclose(c["flat"][:, 7:11], c0["rot"] + c1["rot"])
+    assert np.array_equal(c0["flat"], c1["flat"])
 
 
 def test_allreduce_is_noop_without_process_group(pkg):

@@ -312,3 +312,37 @@ def test_fused_adam_zero_grad_is_identity_and_lr(pkg, dev):
     opt.update_lr(15000)
     assert opt.get_lr(pkg.ParamGroup.kPositions) == pytest.approx(pkg.position_lr(15000, pkg.PositionLRConfig()))
     assert opt.get_lr(pkg.ParamGroup.kPositions) == pytest.approx(1.6e-5, rel=1e-3)
+
+
+def test_compact_exchange_equals_sum_of_views(pkg, orc, dev):
+    """Data-parallel extension: rebuilding the SH gradient of a V-view batch from the gated colour gradients
+    (cugs_sh_backward_views) equals the sum of the per-view render_backward results, and the per-view path
+    with the SH gradient skipped leaves every other gradient unchanged."""
+    w, h, n, deg, V = 200, 150, 4000, 3, 3
+    arrays = pkg.scene.make_gaussians(n, w, h, sh_degree=deg, seed=5, mu_s=-3.6)
+    model = pkg.scene.to_model(arrays, dev)
+    settings = pkg.RenderSettings(active_sh_degree=deg)
+    full_sh = torch.zeros((n, 3, 16), device=dev)
+    full_pos = torch.zeros((n, 3), device=dev)
+    gated_all, centres, pos_sum = [], [], torch.zeros((n, 3), device=dev)
+    for v in range(V):
+        cam = pkg.scene.make_camera(w, h, view=v)
+        g = torch.from_numpy(pkg.scene.make_dl_dcolor(w, h, seed=100 + v)).to(dev)
+        out = pkg.render(model, cam, settings)
+        ref = pkg.render_backward(g, out, model, cam, settings)                        # standard path
+        full_sh += ref.dL_dsh_coeffs
+        full_pos += ref.dL_dpositions
+        gated = torch.empty((n, 3), device=dev)
+        lean = pkg.render_backward(g, out, model, cam, settings, dL_drgb_gated_out=gated)   # exchange path
+        assert lean.dL_dsh_coeffs is None
+        assert max_err_over_max(np_(lean.dL_dpositions), np_(ref.dL_dpositions)) <= 1e-5     # atomics order only
+        pos_sum += lean.dL_dpositions
+        gated_all.append(gated)
+        centres.append(cam.camera_center().tolist())
+        # single view through the exchange entry point (no process group): identical to the standard path
+        one = pkg.parallel.exchange_gradients(lean, gated, model.positions, cam.camera_center(), deg, 16)
+        assert max_err_over_max(np_(one.dL_dsh_coeffs), np_(ref.dL_dsh_coeffs)) <= 1e-5
+        assert one.dL_dopacities.shape == (n, 1) and one.dL_drotations.shape == (n, 4)
+    got = pkg.sh_backward_views(deg, model.positions, torch.stack(gated_all), centres, 16)
+    assert max_err_over_max(np_(got), np_(full_sh)) <= 1e-5
+    assert max_err_over_max(np_(pos_sum), np_(full_pos)) <= 1e-5
