@@ -99,13 +99,14 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     d_means = torch.empty((n, 2), dtype=torch.float32, device=g.device)
     compact = do_allreduce and exchange == "compact"
     gated = torch.empty((n, 3), dtype=torch.float32, device=g.device) if compact else None
+    flat = torch.empty((11 * n,), dtype=torch.float32, device=g.device) if compact else None
     pb = R.project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
                             model.opacities, model.sh_coeffs, proj.radii, cam, deg, settings.scale_modifier,
                             grad_accum=rb.grad_accum, rgb_clamped=proj.rgb, dL_dmeans_2d_out=d_means,
-                            dL_drgb_gated_out=gated, skip_sh_grad=compact)
+                            dL_drgb_gated_out=gated, skip_sh_grad=compact, geom_flat=flat)
     ev[5].record()
     grads = pkg.BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
-                               pb.dL_dsh_coeffs, d_means)
+                               pb.dL_dsh_coeffs, d_means, geom_flat=flat)
     if compact:        # all-gather 12 B/G colour grads + all-reduce 44 B/G geometry grads, SH grads rebuilt locally
         grads = pkg.parallel.exchange_gradients(grads, gated, model.positions, cam.camera_center(), deg,
                                                 int(model.sh_coeffs.shape[2]), all_cam_centers=all_centres)
@@ -236,7 +237,8 @@ def main():
         if forward_only:
             out = pkg.render(model, cam, settings)
             return out.total_pairs, out, None
-        return timed_step(pkg, model, cam, settings, g, events, args.exchange, world > 1, opt, all_centres)
+        # under torch.distributed.run the exchange step always runs (also for a 1-rank rehearsal)
+        return timed_step(pkg, model, cam, settings, g, events, args.exchange, launched, opt, all_centres)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -290,7 +292,7 @@ def main():
             "config": {"workload": wl.name + (" fwd only" if forward_only else " fwd+bwd") + (" +adam" if use_adam else ""),
                        "n_gaussians": wl.n, "width": wl.width, "height": wl.height, "sh_degree": wl.sh_degree,
                        "pairs": int(pairs), "mu_s": wl.mu_s, "views_per_step": n_gpus,
-                       "parallelism": f"dp{n_gpus}-views" + (f"+rccl-{args.exchange}" if n_gpus > 1 else "")},
+                       "parallelism": f"dp{n_gpus}-views" + (f"+rccl-{args.exchange}" if launched else "")},
             "roofline": roofline, "frame_roofline": frame,
             "stages_ms": {k: round(v, 4) for k, v in stages_ms.items()},
         }

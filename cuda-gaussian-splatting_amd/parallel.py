@@ -49,47 +49,43 @@ def allreduce_gradients(grads: BackwardOutput, group: Optional[dist.ProcessGroup
 #     camera centres) and rebuilds the summed SH gradient locally with cugs_sh_backward_views, in view
 #     (= rank) order: the result is bit-identical on every rank, which an all-reduce does not promise.
 # --------------------------------------------------------------------------------------
-GEOM_FIELDS = ("dL_dpositions", "dL_dopacities", "dL_dscales", "dL_drotations")
-GEOM_WIDTHS = (3, 1, 3, 4)
-
-
 def collect_views(grads: BackwardOutput, gated_rgb: torch.Tensor, cam_center: torch.Tensor,
                   group: Optional[dist.ProcessGroup] = None):
     """The collective half of the compact exchange (device-agnostic: RCCL on GPUs, gloo on CPU).
-    Returns (geom_flat_summed [N,11], gated_views [V,N,3], centres [V,3])."""
+    The geometry gradients are all-reduced IN PLACE: as one collective when they are views of one flat
+    buffer (render_backward(..., geom_flat=...)), else one collective each.
+    Returns (gated_views [V,N,3], centres [V,3])."""
     n = gated_rgb.shape[0]
-    flat = torch.cat([getattr(grads, f).reshape(n, w) for f, w in zip(GEOM_FIELDS, GEOM_WIDTHS)], dim=1).contiguous()
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return flat, gated_rgb.reshape(1, n, 3), cam_center.reshape(1, 3)
-    world = dist.get_world_size(group)
+    if not dist.is_initialized():
+        return gated_rgb.reshape(1, n, 3), cam_center.reshape(1, 3)
+    world = dist.get_world_size(group)          # a 1-rank group still goes through the collectives
     # outputs are the rank-order concatenation along dim 0 (the shape both RCCL and gloo accept)
     views = torch.empty((world * n, 3), dtype=gated_rgb.dtype, device=gated_rgb.device)
     centres = torch.empty((world * 3,), dtype=cam_center.dtype, device=cam_center.device)
-    works = [dist.all_gather_into_tensor(views, gated_rgb.reshape(n, 3).contiguous(), group=group, async_op=True),
-             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True),
-             dist.all_gather_into_tensor(centres, cam_center.reshape(3).contiguous(), group=group, async_op=True)]
+    geom = [grads.geom_flat] if grads.geom_flat is not None else \
+        [grads.dL_dpositions, grads.dL_dopacities, grads.dL_dscales, grads.dL_drotations]
+    works = [dist.all_gather_into_tensor(views, gated_rgb.reshape(n, 3).contiguous(), group=group, async_op=True)]
+    works += [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in geom]
+    works += [dist.all_gather_into_tensor(centres, cam_center.reshape(3).contiguous(), group=group, async_op=True)]
     for w in works:
         w.wait()
-    return flat, views.view(world, n, 3), centres.view(world, 3)
+    return views.view(world, n, 3), centres.view(world, 3)
 
 
 def exchange_gradients(grads: BackwardOutput, gated_rgb: torch.Tensor, positions: torch.Tensor,
                        cam_center, active_sh_degree: int, num_coeffs: int,
                        group: Optional[dist.ProcessGroup] = None, all_cam_centers=None) -> BackwardOutput:
-    """Compact data-parallel exchange.  `grads` comes from render_backward(..., dL_drgb_gated_out=gated_rgb)
-    (its dL_dsh_coeffs is None).  Returns a BackwardOutput whose five parameter gradients are the sums
-    over all ranks' views; dL_dmeans_2d stays per-view.  `all_cam_centers` ([V,3] host values, if every
-    rank knows every view's camera) avoids the device-to-host read of the gathered centres."""
+    """Compact data-parallel exchange.  `grads` comes from
+    render_backward(..., dL_drgb_gated_out=gated_rgb[, geom_flat=...]) (its dL_dsh_coeffs is None).
+    On return the four geometry gradients hold the sums over all ranks' views (in place) and
+    dL_dsh_coeffs is the summed SH gradient; dL_dmeans_2d stays per-view.  `all_cam_centers` ([V,3] host
+    values, if every rank knows every view's camera) avoids the device-to-host read of the gathered centres."""
     from .rasterizer import sh_backward_views
     cc = torch.as_tensor(cam_center, dtype=torch.float32, device=gated_rgb.device).reshape(3)
-    flat, views, centres = collect_views(grads, gated_rgb, cc, group)
+    views, centres = collect_views(grads, gated_rgb, cc, group)
     host_centres = all_cam_centers if all_cam_centers is not None else centres.cpu().tolist()
-    d_sh = sh_backward_views(active_sh_degree, positions, views, host_centres, num_coeffs)
-    parts = torch.split(flat, GEOM_WIDTHS, dim=1)
-    n = flat.shape[0]
-    return BackwardOutput(dL_dpositions=parts[0].contiguous(), dL_drotations=parts[3].contiguous(),
-                          dL_dscales=parts[2].contiguous(), dL_dopacities=parts[1].contiguous().reshape(n, 1),
-                          dL_dsh_coeffs=d_sh, dL_dmeans_2d=grads.dL_dmeans_2d)
+    grads.dL_dsh_coeffs = sh_backward_views(active_sh_degree, positions, views, host_centres, num_coeffs)
+    return grads
 
 
 def wait_all(works: Sequence) -> None:

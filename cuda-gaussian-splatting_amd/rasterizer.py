@@ -223,13 +223,17 @@ def project_backward(dL_dmeans_2d: Optional[torch.Tensor], dL_dcov_2d_inv: Optio
                      grad_accum: Optional[torch.Tensor] = None, rgb_clamped: Optional[torch.Tensor] = None,
                      dL_dmeans_2d_out: Optional[torch.Tensor] = None,
                      dL_drgb_gated_out: Optional[torch.Tensor] = None,
-                     skip_sh_grad: bool = False) -> ProjectionBackwardOutput:
+                     skip_sh_grad: bool = False,
+                     geom_flat: Optional[torch.Tensor] = None) -> ProjectionBackwardOutput:
     _torch_check(positions.is_cuda, "positions must be on CUDA")
     n = int(positions.shape[0])
     dev = positions.device
     f = dict(dtype=torch.float32, device=dev)
-    d_pos, d_rot = torch.empty((n, 3), **f), torch.empty((n, 4), **f)
-    d_scl, d_opa = torch.empty((n, 3), **f), torch.empty((n, 1), **f)
+    if geom_flat is not None:      # one allocation [rot 4N | pos 3N | scl 3N | opa N]: all-reduced in place
+        d_rot, d_pos, d_scl, d_opa = geometry_views(geom_flat, n)
+    else:
+        d_pos, d_rot = torch.empty((n, 3), **f), torch.empty((n, 4), **f)
+        d_scl, d_opa = torch.empty((n, 3), **f), torch.empty((n, 1), **f)
     sh_c = _f32c(sh_coeffs)
     d_sh = None if skip_sh_grad else torch.empty_like(sh_c)      # skipped in the data-parallel exchange
     if n == 0:
@@ -246,6 +250,14 @@ def project_backward(dL_dmeans_2d: Optional[torch.Tensor], dL_dcov_2d_inv: Optio
                                     _ptr(dL_drgb_gated_out), _stream(dev)),
           "cugs_project_backward")
     return ProjectionBackwardOutput(d_pos, d_rot, d_scl, d_opa, d_sh)
+
+
+def geometry_views(flat: torch.Tensor, n: int):
+    """Views (rot [N,4], pos [N,3], scl [N,3], opa [N,1]) into a flat [11N] float32 buffer.  Rotations come
+    first so that their rows stay 16-byte aligned for the kernel's float4 stores."""
+    _torch_check(flat.numel() == 11 * n and flat.is_contiguous(), "geom_flat must be a contiguous [11*N] tensor")
+    return (flat[0:4 * n].view(n, 4), flat[4 * n:7 * n].view(n, 3), flat[7 * n:10 * n].view(n, 3),
+            flat[10 * n:11 * n].view(n, 1))
 
 
 def sh_backward_views(degree: int, positions: torch.Tensor, gated_rgb_views: torch.Tensor,
@@ -299,7 +311,8 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings) -
 
 def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: GaussianModel,
                     camera: CameraInfo, settings: RenderSettings,
-                    dL_drgb_gated_out: Optional[torch.Tensor] = None) -> BackwardOutput:
+                    dL_drgb_gated_out: Optional[torch.Tensor] = None,
+                    geom_flat: Optional[torch.Tensor] = None) -> BackwardOutput:
     """`dL_drgb_gated_out` ([N,3], optional, not in the reference): when given, the per-view SH gradient
     is NOT materialised (dL_dsh_coeffs is None) and the gated colour gradient is written there instead,
     for parallel.exchange_gradients() to rebuild the summed SH gradient after the all-gather."""
@@ -322,6 +335,6 @@ def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: Ga
                           model.opacities, model.sh_coeffs, render_out.radii, camera, active_degree,
                           settings.scale_modifier, grad_accum=rb.grad_accum, rgb_clamped=render_out.rgb,
                           dL_dmeans_2d_out=d_means_2d, dL_drgb_gated_out=dL_drgb_gated_out,
-                          skip_sh_grad=dL_drgb_gated_out is not None)
+                          skip_sh_grad=dL_drgb_gated_out is not None, geom_flat=geom_flat)
     return BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
-                          pb.dL_dsh_coeffs, d_means_2d)
+                          pb.dL_dsh_coeffs, d_means_2d, geom_flat=geom_flat)

@@ -197,3 +197,4 @@ class BackwardOutput:
     dL_dopacities: torch.Tensor
     dL_dsh_coeffs: torch.Tensor
     dL_dmeans_2d: torch.Tensor
+    geom_flat: Optional[torch.Tensor] = None    # [11N] buffer the four geometry gradients are views of (DP exchange)

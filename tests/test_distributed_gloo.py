@@ -31,9 +31,9 @@ def _worker(rank, world, port, q):
         g2 = pkg.BackwardOutput(mk(n, 3), mk(n, 4), mk(n, 3), mk(n, 1), None, mk(n, 2))
         gated, centre = mk(n, 3), mk(3)
         mine = dict(pos=g2.dL_dpositions.clone(), rot=g2.dL_drotations.clone(), gated=gated.clone(), centre=centre.clone())
-        flat, gviews, centres = pkg.parallel.collect_views(g2, gated, centre)
-        compact = dict(flat=flat.numpy(), views=gviews.numpy(), centres=centres.numpy(),
-                       **{k: v.numpy() for k, v in mine.items()})
+        gviews, centres = pkg.parallel.collect_views(g2, gated, centre)        # geometry reduced in place
+        compact = dict(sum_pos=g2.dL_dpositions.numpy(), sum_rot=g2.dL_drotations.numpy(), views=gviews.numpy(),
+                       centres=centres.numpy(), **{k: v.numpy() for k, v in mine.items()})
         # numpy: pickled by value (torch tensors would travel as shared-memory handles)
         q.put((rank, {k: v.numpy() for k, v in local.items()}, {k: v.numpy() for k, v in out.items()}, views, compact))
     finally:
@@ -56,12 +56,12 @@ def test_allreduce_gradients_world2_gloo():
         else:
             assert np.allclose(o0[f], l0[f] + l1[f]) and np.array_equal(o0[f], o1[f])
     assert set(v0).isdisjoint(v1) and v0 == [0, 2, 4, 6] and v1 == [1, 3, 5, 7]
-    # compact exchange: views stacked in RANK order on both ranks, geometry summed, layout pos|opa|scl|rot
+    # compact exchange: views stacked in RANK order on both ranks, geometry summed in place
     for c in (c0, c1):
         assert np.array_equal(c["views"][0], c0["gated"]) and np.array_equal(c["views"][1], c1["gated"])
         assert np.array_equal(c["centres"][0], c0["centre"]) and np.array_equal(c["centres"][1], c1["centre"])
-        assert np.allclose(c["flat"][:, 0:3], c0["pos"] + c1["pos"]) and np.allclose(c["flat"][:, 7:11], c0["rot"] + c1["rot"])
-    assert np.array_equal(c0["flat"], c1["flat"])
+        assert np.allclose(c["sum_pos"], c0["pos"] + c1["pos"]) and np.allclose(c["sum_rot"], c0["rot"] + c1["rot"])
+    assert np.array_equal(c0["sum_pos"], c1["sum_pos"])
 
 
 def test_allreduce_is_noop_without_process_group(pkg):

@@ -333,8 +333,11 @@ def test_compact_exchange_equals_sum_of_views(pkg, orc, dev):
         full_sh += ref.dL_dsh_coeffs
         full_pos += ref.dL_dpositions
         gated = torch.empty((n, 3), device=dev)
-        lean = pkg.render_backward(g, out, model, cam, settings, dL_drgb_gated_out=gated)   # exchange path
-        assert lean.dL_dsh_coeffs is None
+        flat = torch.empty((11 * n,), device=dev)
+        lean = pkg.render_backward(g, out, model, cam, settings, dL_drgb_gated_out=gated, geom_flat=flat)   # exchange path
+        assert lean.dL_dsh_coeffs is None and lean.dL_drotations.data_ptr() == flat.data_ptr()
+        assert max_err_over_max(np_(lean.dL_drotations), np_(ref.dL_drotations)) <= 1e-5
+        assert max_err_over_max(np_(lean.dL_dopacities), np_(ref.dL_dopacities)) <= 1e-5
         assert max_err_over_max(np_(lean.dL_dpositions), np_(ref.dL_dpositions)) <= 1e-5     # atomics order only
         pos_sum += lean.dL_dpositions
         gated_all.append(gated)
