@@ -57,6 +57,8 @@ SIGNATURES = {
     "cugs_adam_bias_correction": (None, [_F, _F, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cugs_fused_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
     "cugs_fused_adam_groups": (_I, [C.POINTER(AdamGroup), _I, _F, _F, _F, _F, _F, _P]),
+    "cugs_loss_workspace_bytes": (C.c_size_t, [_I, _I]),
+    "cugs_combined_loss": (_I, [_I, _I, _P, _P, _F, _I, _P, C.c_size_t, _P, _P, _P, _P]),
     "cugs_device_count": (_I, [C.POINTER(C.c_int)]),
 }
 

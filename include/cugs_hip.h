@@ -187,6 +187,17 @@ typedef struct cugs_adam_group {
 int cugs_fused_adam_groups(const cugs_adam_group* groups_host, int ngroups, float beta1,
                            float beta2, float eps, float bc1, float bc2, void* stream);
 
+/* ---- N1: combined_loss + dL/dcolor (training/loss.cpp:88-140, trainer.cpp:214-217) ----
+ * L = (1-lambda) mean|x-y| + lambda (1 - mean SSIM), SSIM with a window_size x window_size sigma-1.5
+ * Gaussian window (odd, 3..15; the reference default is 11), zero padding, C1 = 1e-4, C2 = 9e-4.
+ * rendered, target: [H,W,3].  loss_out: DEVICE float[4] = {loss, L1, mean SSIM, 1 - mean SSIM} (no host
+ * sync).  ssim_map ([H,W], mean over channels = ssim(), loss.cpp:93) and dL_dcolor ([H,W,3] = d loss /
+ * d rendered, what autograd returns at trainer.cpp:217) are optional.  workspace: cugs_loss_workspace_bytes. */
+size_t cugs_loss_workspace_bytes(int width, int height);
+int cugs_combined_loss(int width, int height, const float* rendered, const float* target, float lambda,
+                       int window_size, void* workspace, size_t workspace_bytes, float* loss_out,
+                       float* ssim_map, float* dL_dcolor, void* stream);
+
 /* Device properties the host side needs without linking the HIP runtime itself. */
 int cugs_device_count(int* count_host);
 
