@@ -54,6 +54,10 @@ int main(int argc, char** argv) {
         opt.apply_gradients(grads);
         opt.step();
         fprintf(stderr, "[driver] adam done\n");
+        // N1 through the C++ host: loss + dL/dcolor of the render against the flipped image as a target
+        auto lg = cugs_hip::combined_loss_and_grad(out.color, out.color.flip(0).contiguous());
+        save(d + "/out_loss.bin", lg.loss.reshape({1}));
+        save(d + "/out_loss_grad.bin", lg.dL_dcolor);
         save(d + "/out_color.bin", out.color);
         save(d + "/out_n_contrib.bin", out.n_contrib);
         save(d + "/out_indices.bin", out.gaussian_indices);

@@ -293,6 +293,50 @@ BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutpu
     return o;
 }
 
+namespace {
+void validate_pair(const torch::Tensor& rendered, const torch::Tensor& target) {               // loss.cpp:14-34
+    for (const torch::Tensor* img : {&rendered, &target}) {
+        TORCH_CHECK(img->dim() == 3, "image must be 3-dimensional [H, W, 3], got ", img->dim(), " dims");
+        TORCH_CHECK(img->size(2) == 3, "image must have 3 channels, got ", img->size(2));
+        TORCH_CHECK(img->dtype() == torch::kFloat32, "image must be float32, got ", img->dtype());
+        TORCH_CHECK(img->is_cuda(), "image must be on a CUDA device");
+    }
+    TORCH_CHECK(rendered.sizes() == target.sizes(), "rendered and target must have the same shape, got ",
+                rendered.sizes(), " vs ", target.sizes());
+}
+torch::Tensor run_loss(const torch::Tensor& rendered, const torch::Tensor& target, float lambda_, int window_size,
+                       torch::Tensor* ssim_map, torch::Tensor* grad) {
+    validate_pair(rendered, target);
+    TORCH_CHECK(window_size % 2 == 1, "window_size must be odd, got ", window_size);               // loss.cpp:96-97
+    TORCH_CHECK(window_size >= 3, "window_size must be >= 3, got ", window_size);
+    const int h = static_cast<int>(rendered.size(0)), w = static_cast<int>(rendered.size(1));
+    auto r = rendered.contiguous(), t = target.contiguous();
+    auto out = torch::empty({4}, fopt(rendered));
+    if (ssim_map) *ssim_map = torch::empty({h, w}, fopt(rendered));
+    if (grad) *grad = torch::empty({h, w, 3}, fopt(rendered));
+    auto ws = workspace(rendered.device(), cugs_loss_workspace_bytes(w, h), 2);
+    check(cugs_combined_loss(w, h, ptr<float>(r), ptr<float>(t), lambda_, window_size, ws.data_ptr(), ws.numel(),
+                             ptr<float>(out), ssim_map ? ptr<float>(*ssim_map) : nullptr,
+                             grad ? ptr<float>(*grad) : nullptr, stream_of(rendered)), "cugs_combined_loss");
+    return out;
+}
+}  // namespace
+
+LossAndGrad combined_loss_and_grad(const torch::Tensor& rendered, const torch::Tensor& target, float lambda_, bool want_grad) {
+    LossAndGrad o;
+    auto out = run_loss(rendered, target, lambda_, 11, nullptr, want_grad ? &o.dL_dcolor : nullptr);
+    o.loss = out[0]; o.l1 = out[1]; o.ssim_mean = out[2];
+    return o;
+}
+torch::Tensor combined_loss(const torch::Tensor& rendered, const torch::Tensor& target, float lambda_) {
+    return run_loss(rendered, target, lambda_, 11, nullptr, nullptr)[0];
+}
+torch::Tensor ssim(const torch::Tensor& rendered, const torch::Tensor& target, int window_size) {
+    torch::Tensor map;
+    run_loss(rendered, target, 0.2f, window_size, &map, nullptr);
+    return map;
+}
+
 FusedAdam::FusedAdam(std::array<torch::Tensor, 5> params, std::array<float, 5> lrs, AdamHyper h)
     : params_(std::move(params)), lrs_(lrs), h_(h) {
     for (int i = 0; i < 5; ++i) { m_[i] = torch::zeros_like(params_[i]); v_[i] = torch::zeros_like(params_[i]); }

@@ -75,6 +75,14 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
 BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutput& render_out,
                                const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings);
 
+// training/loss.hpp:21-52 + the autograd step of trainer.cpp:214-217 in two launches.
+// Scalars are 0-dim device tensors, as in the reference.
+struct LossAndGrad { torch::Tensor loss, l1, ssim_mean, dL_dcolor; };
+LossAndGrad combined_loss_and_grad(const torch::Tensor& rendered, const torch::Tensor& target, float lambda_ = 0.2f,
+                                   bool want_grad = true);
+torch::Tensor combined_loss(const torch::Tensor& rendered, const torch::Tensor& target, float lambda_ = 0.2f);
+torch::Tensor ssim(const torch::Tensor& rendered, const torch::Tensor& target, int window_size = 11);
+
 // optimizer/fused_adam.hpp:29-106 on raw tensors (group order: positions, sh, opacities, scales, rotations)
 struct AdamHyper { float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-15f; };
 class FusedAdam {

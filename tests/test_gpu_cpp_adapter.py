@@ -49,6 +49,10 @@ def test_cpp_adapter_matches_python_host(pkg, dev, tmp_path):
     assert np.array_equal(rd("out_indices.bin", np.int32, (-1,)), np_(out.gaussian_indices))
     assert np.array_equal(rd("out_n_contrib.bin", np.int32, (h, w)), np_(out.n_contrib))
     assert np.array_equal(rd("out_color.bin", np.uint32, (h, w, 3)), np_(out.color).view(np.uint32))
+    # N1 through the C++ host equals the Python host on the same (bit-identical) image
+    loss_py, grad_py = pkg.combined_loss_and_grad(out.color, out.color.flip(0).contiguous())
+    assert abs(float(rd("out_loss.bin", np.float32, (1,))[0]) - float(loss_py)) <= 1e-6
+    assert max_err_over_max(rd("out_loss_grad.bin", np.float32, (h, w, 3)), np_(grad_py)) <= 1e-6
     # gradients: same kernels, atomic order may differ run to run
     assert max_err_over_max(rd("out_dpos.bin", np.float32, (n, 3)), np_(grads.dL_dpositions)) <= 1e-5
     assert max_err_over_max(rd("out_dsh.bin", np.float32, (n, 3, 16)), np_(grads.dL_dsh_coeffs)) <= 1e-5
