@@ -26,8 +26,45 @@ constexpr int MAX_E = LT + 2 * MAX_R;
 
 struct Window { float w[2 * MAX_R + 1]; int r; };
 
-__device__ __forceinline__ float fetch(const float* __restrict__ img, int x, int y, int ch, int w, int h) {
-    return (x >= 0 && x < w && y >= 0 && y < h) ? img[((int64_t)y * w + x) * 3 + ch] : 0.0f;   // zero padding
+// Tiles keep the image's interleaved [.,.,3] layout in LDS: a tile row of E pixels is E*3 consecutive floats,
+// loaded once for all three channels; the horizontal pass treats it as 48 output "columns" with a tap
+// stride of 3 floats.
+// With a compile-time radius every thread first issues all its loads (NIMG images x <= 8 floats) and only then
+// writes LDS, so one HBM latency is paid per tile instead of one per element.
+template <int RT, int NIMG>
+__device__ __forceinline__ void load_tiles3(const float* const (&img)[NIMG], float* const (&s_t)[NIMG], int tx0, int ty0,
+                                            int R, int E, int w, int h) {
+    const int row_f = E * 3, total = E * row_f, w3 = w * 3;
+    if constexpr (RT > 0) {
+        constexpr int ET = LT + 2 * RT, PER = (ET * ET * 3 + CUGS_BLOCK - 1) / CUGS_BLOCK;
+        float v[NIMG][PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = (int)threadIdx.x + i * CUGS_BLOCK;
+            const int ey = e / row_f, ef = e - ey * row_f;
+            const int gy = ty0 + ey - R, gxf = (tx0 - R) * 3 + ef;      // float index within the image row
+            const bool ok = e < total && gy >= 0 && gy < h && gxf >= 0 && gxf < w3;
+            const int64_t off = ok ? (int64_t)gy * w3 + gxf : 0;
+#pragma unroll
+            for (int m = 0; m < NIMG; ++m) { const float t = img[m][off]; v[m][i] = ok ? t : 0.0f; }   // zero padding
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = (int)threadIdx.x + i * CUGS_BLOCK;
+            if (e < total) {
+#pragma unroll
+                for (int m = 0; m < NIMG; ++m) s_t[m][e] = v[m][i];
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += CUGS_BLOCK) {
+            const int ey = e / row_f, ef = e - ey * row_f;
+            const int gy = ty0 + ey - R, gxf = (tx0 - R) * 3 + ef;
+            const bool ok = gy >= 0 && gy < h && gxf >= 0 && gxf < w3;
+#pragma unroll
+            for (int m = 0; m < NIMG; ++m) s_t[m][e] = ok ? img[m][(int64_t)gy * w3 + gxf] : 0.0f;
+        }
+    }
 }
 
 template <int RT>
@@ -35,45 +72,87 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_stats(int w, int h, Window 
                                                            const float* __restrict__ yt, float* __restrict__ d_m,
                                                            float* __restrict__ d_p, float* __restrict__ d_r,
                                                            float* __restrict__ ssim_map, double* __restrict__ sums) {
-    __shared__ float s_x[MAX_E * MAX_E], s_y[MAX_E * MAX_E];
-    __shared__ float s_h[5][MAX_E * LT];
+    constexpr int CW = LT * 3;                                           // 48 float columns per tile row
+    // With a compile-time radius the horizontal sums pass through registers and overwrite the input tiles,
+    // so a block holds max(inputs, sums) instead of both (25 KB for the 11-tap window: 6 blocks per CU).
+    constexpr bool ALIAS = RT > 0;
+    constexpr int ET = ALIAS ? LT + 2 * RT : MAX_E;
+    constexpr int IN_F = ET * ET * 3, H_F = ET * CW;
+    constexpr int POOL = ALIAS ? (2 * IN_F > 5 * H_F ? 2 * IN_F : 5 * H_F) : 2 * IN_F + 5 * H_F;
+    __shared__ float s_pool[POOL];
     __shared__ double s_red[2][4];
+    float* const s_x = s_pool;
+    float* const s_y = s_pool + IN_F;
+    float* const s_hp = ALIAS ? s_pool : s_pool + 2 * IN_F;             // plane k at s_hp + k * H_F
     const int R = RT > 0 ? RT : win.r, E = LT + 2 * R;      // RT > 0: compile-time radius, loops fully unrolled
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT;
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int px = tx0 + lx, py = ty0 + ly;
     const bool inside = px < w && py < h;
-    float ssim_sum = 0.0f;          // over channels, for the map
-    double l1_acc = 0.0, ss_acc = 0.0;
-
-    for (int ch = 0; ch < 3; ++ch) {
-        for (int e = tid; e < E * E; e += CUGS_BLOCK) {
-            const int ey = e / E, ex = e - ey * E;
-            s_x[e] = fetch(xr, tx0 + ex - R, ty0 + ey - R, ch, w, h);
-            s_y[e] = fetch(yt, tx0 + ex - R, ty0 + ey - R, ch, w, h);
-        }
-        __syncthreads();
-        // horizontal pass: E rows x 16 columns
-        for (int e = tid; e < E * LT; e += CUGS_BLOCK) {
-            const int ey = e / LT, cx = e - ey * LT;
-            float a = 0.0f, b = 0.0f, aa = 0.0f, bb = 0.0f, ab = 0.0f;
+    {
+        const float* const imgs[2] = {xr, yt};
+        float* const dst[2] = {s_x, s_y};
+        load_tiles3<RT, 2>(imgs, dst, tx0, ty0, R, E, w, h);
+    }
+    __syncthreads();
+    // |x - y| at this thread's pixel, read before the tiles can be overwritten
+    float l1c[3];
 #pragma unroll
-            for (int k = 0; k <= 2 * R; ++k) {
-                const float wk = win.w[k], xv = s_x[ey * E + cx + k], yv = s_y[ey * E + cx + k];
-                a = fmaf(wk, xv, a); b = fmaf(wk, yv, b);
-                aa = fmaf(wk, xv * xv, aa); bb = fmaf(wk, yv * yv, bb); ab = fmaf(wk, xv * yv, ab);
-            }
-            s_h[0][e] = a; s_h[1][e] = b; s_h[2][e] = aa; s_h[3][e] = bb; s_h[4][e] = ab;
+    for (int ch = 0; ch < 3; ++ch) {
+        const int c = ((ly + R) * E + lx + R) * 3 + ch;
+        l1c[ch] = fabsf(s_x[c] - s_y[c]);
+    }
+    // horizontal pass: E rows x 48 float columns (16 pixels x 3 channels), tap stride 3
+    auto hsum = [&](int e, float (&o)[5]) {
+        const int ey = e / CW, cf = e - ey * CW;
+        const float* rx = s_x + ey * E * 3 + cf;
+        const float* ry = s_y + ey * E * 3 + cf;
+        float a = 0.0f, b = 0.0f, aa = 0.0f, bb = 0.0f, ab = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) {
+            const float wk = win.w[k], xv = rx[3 * k], yv = ry[3 * k];
+            a = fmaf(wk, xv, a); b = fmaf(wk, yv, b);
+            aa = fmaf(wk, xv * xv, aa); bb = fmaf(wk, yv * yv, bb); ab = fmaf(wk, xv * yv, ab);
         }
-        __syncthreads();
-        // vertical pass at this thread's pixel
+        o[0] = a; o[1] = b; o[2] = aa; o[3] = bb; o[4] = ab;
+    };
+    if constexpr (ALIAS) {
+        constexpr int PER_H = (H_F + CUGS_BLOCK - 1) / CUGS_BLOCK;
+        float acc[PER_H][5];
+#pragma unroll
+        for (int i = 0; i < PER_H; ++i) {
+            const int e = tid + i * CUGS_BLOCK;
+            if (e < H_F) hsum(e, acc[i]);
+        }
+        __syncthreads();                                                 // every read of the input tiles is done
+#pragma unroll
+        for (int i = 0; i < PER_H; ++i) {
+            const int e = tid + i * CUGS_BLOCK;
+            if (e < H_F) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) s_hp[k * H_F + e] = acc[i][k];
+            }
+        }
+    } else {
+        for (int e = tid; e < E * CW; e += CUGS_BLOCK) {
+            float o[5];
+            hsum(e, o);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) s_hp[k * H_F + e] = o[k];
+        }
+    }
+    __syncthreads();
+    float ssim_sum = 0.0f;
+    double l1_acc = 0.0, ss_acc = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
         float m = 0.0f, n = 0.0f, p = 0.0f, q = 0.0f, r = 0.0f;
 #pragma unroll
         for (int k = 0; k <= 2 * R; ++k) {
             const float wk = win.w[k];
-            const int e = (ly + k) * LT + lx;
-            m = fmaf(wk, s_h[0][e], m); n = fmaf(wk, s_h[1][e], n); p = fmaf(wk, s_h[2][e], p);
-            q = fmaf(wk, s_h[3][e], q); r = fmaf(wk, s_h[4][e], r);
+            const int e = (ly + k) * CW + lx * 3 + ch;
+            m = fmaf(wk, s_hp[e], m); n = fmaf(wk, s_hp[H_F + e], n); p = fmaf(wk, s_hp[2 * H_F + e], p);
+            q = fmaf(wk, s_hp[3 * H_F + e], q); r = fmaf(wk, s_hp[4 * H_F + e], r);
         }
         if (inside) {
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
@@ -88,9 +167,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_stats(int w, int h, Window 
             d_r[o] = 2.0f * A1 * inv;
             ssim_sum += S;
             ss_acc += (double)S;
-            l1_acc += (double)fabsf(s_x[(ly + R) * E + lx + R] - s_y[(ly + R) * E + lx + R]);
+            l1_acc += (double)l1c[ch];
         }
-        __syncthreads();            // tiles are reloaded for the next channel
     }
     if (inside && ssim_map) ssim_map[(int64_t)py * w + px] = ssim_sum / 3.0f;   // mean(dim=2), loss.cpp:128
 
@@ -108,51 +186,84 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_grad(int w, int h, Window w
                                                           const float* __restrict__ xr, const float* __restrict__ yt,
                                                           const float* __restrict__ d_m, const float* __restrict__ d_p,
                                                           const float* __restrict__ d_r, float* __restrict__ dL_dx) {
-    __shared__ float s_a[3][MAX_E * MAX_E];
-    __shared__ float s_h[3][MAX_E * LT];
-    const int R = RT > 0 ? RT : win.r, E = LT + 2 * R;      // RT > 0: compile-time radius, loops fully unrolled
+    constexpr int CW = LT * 3;
+    constexpr bool ALIAS = RT > 0;                                       // as in k_ssim_stats
+    constexpr int ET = ALIAS ? LT + 2 * RT : MAX_E;
+    constexpr int IN_F = ET * ET * 3, H_F = ET * CW;
+    __shared__ float s_pool[ALIAS ? 3 * IN_F : 3 * IN_F + 3 * H_F];
+    float* const s_a[3] = {s_pool, s_pool + IN_F, s_pool + 2 * IN_F};
+    float* const s_hp = ALIAS ? s_pool : s_pool + 3 * IN_F;
+    const int R = RT > 0 ? RT : win.r, E = LT + 2 * R;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT;
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int px = tx0 + lx, py = ty0 + ly;
     const bool inside = px < w && py < h;
     const float inv_n = 1.0f / ((float)w * (float)h * 3.0f);
-
-    for (int ch = 0; ch < 3; ++ch) {
-        for (int e = tid; e < E * E; e += CUGS_BLOCK) {
-            const int ey = e / E, ex = e - ey * E;
-            const int gx = tx0 + ex - R, gy = ty0 + ey - R;
-            s_a[0][e] = fetch(d_m, gx, gy, ch, w, h);
-            s_a[1][e] = fetch(d_p, gx, gy, ch, w, h);
-            s_a[2][e] = fetch(d_r, gx, gy, ch, w, h);
-        }
-        __syncthreads();
-        for (int e = tid; e < E * LT; e += CUGS_BLOCK) {
-            const int ey = e / LT, cx = e - ey * LT;
-            float a = 0.0f, b = 0.0f, c = 0.0f;
+    float xv[3] = {0.0f, 0.0f, 0.0f}, yv[3] = {0.0f, 0.0f, 0.0f};      // issued with the tile loads, used at the end
+    if (inside) {
+        const int64_t o = ((int64_t)py * w + px) * 3;
 #pragma unroll
-            for (int k = 0; k <= 2 * R; ++k) {
-                const float wk = win.w[k];
-                a = fmaf(wk, s_a[0][ey * E + cx + k], a);
-                b = fmaf(wk, s_a[1][ey * E + cx + k], b);
-                c = fmaf(wk, s_a[2][ey * E + cx + k], c);
-            }
-            s_h[0][e] = a; s_h[1][e] = b; s_h[2][e] = c;
+        for (int ch = 0; ch < 3; ++ch) { xv[ch] = xr[o + ch]; yv[ch] = yt[o + ch]; }
+    }
+    {
+        const float* const imgs[3] = {d_m, d_p, d_r};
+        float* const dst[3] = {s_a[0], s_a[1], s_a[2]};
+        load_tiles3<RT, 3>(imgs, dst, tx0, ty0, R, E, w, h);
+    }
+    __syncthreads();
+    auto hsum = [&](int e, float (&o)[3]) {
+        const int ey = e / CW, cf = e - ey * CW;
+        const int base = ey * E * 3 + cf;
+        float a = 0.0f, b = 0.0f, c = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) {
+            const float wk = win.w[k];
+            a = fmaf(wk, s_a[0][base + 3 * k], a);
+            b = fmaf(wk, s_a[1][base + 3 * k], b);
+            c = fmaf(wk, s_a[2][base + 3 * k], c);
+        }
+        o[0] = a; o[1] = b; o[2] = c;
+    };
+    if constexpr (ALIAS) {
+        constexpr int PER_H = (H_F + CUGS_BLOCK - 1) / CUGS_BLOCK;
+        float acc[PER_H][3];
+#pragma unroll
+        for (int i = 0; i < PER_H; ++i) {
+            const int e = tid + i * CUGS_BLOCK;
+            if (e < H_F) hsum(e, acc[i]);
         }
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER_H; ++i) {
+            const int e = tid + i * CUGS_BLOCK;
+            if (e < H_F) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s_hp[k * H_F + e] = acc[i][k];
+            }
+        }
+    } else {
+        for (int e = tid; e < E * CW; e += CUGS_BLOCK) {
+            float o[3];
+            hsum(e, o);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_hp[k * H_F + e] = o[k];
+        }
+    }
+    __syncthreads();
+    if (!inside) return;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
         float gm = 0.0f, gp = 0.0f, gr = 0.0f;
 #pragma unroll
         for (int k = 0; k <= 2 * R; ++k) {
             const float wk = win.w[k];
-            const int e = (ly + k) * LT + lx;
-            gm = fmaf(wk, s_h[0][e], gm); gp = fmaf(wk, s_h[1][e], gp); gr = fmaf(wk, s_h[2][e], gr);
+            const int e = (ly + k) * CW + lx * 3 + ch;
+            gm = fmaf(wk, s_hp[e], gm); gp = fmaf(wk, s_hp[H_F + e], gp); gr = fmaf(wk, s_hp[2 * H_F + e], gr);
         }
-        if (inside) {
-            const int64_t o = ((int64_t)py * w + px) * 3 + ch;
-            const float x = xr[o], y = yt[o], d = x - y;
-            const float sgn = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);          // d|x|/dx, 0 at 0 like libtorch
-            dL_dx[o] = (1.0f - lambda) * sgn * inv_n - lambda * inv_n * (gm + 2.0f * x * gp + y * gr);
-        }
-        __syncthreads();
+        const int64_t o = ((int64_t)py * w + px) * 3 + ch;
+        const float x = xv[ch], y = yv[ch], d = x - y;
+        const float sgn = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);          // d|x|/dx, 0 at 0 like libtorch
+        dL_dx[o] = (1.0f - lambda) * sgn * inv_n - lambda * inv_n * (gm + 2.0f * x * gp + y * gr);
     }
 }
 

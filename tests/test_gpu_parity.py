@@ -64,7 +64,8 @@ def test_projection_scale_modifier_and_pose(pkg, orc, dev, scale_mod, view):
 
 
 @pytest.mark.parametrize("n,w,h,mu_s", [(20000, 640, 360, -4.6), (3000, 250, 130, -3.0), (1, 64, 48, -2.0),
-                                         (70000, 1920, 1080, -4.6)])
+                                         (70000, 1920, 1080, -4.6),
+                                         (3000, 4112, 4112, -2.0)])   # 66049 tiles: tile ids wider than 16 bits, 3 passes
 def test_sort_parity_bit_exact(pkg, orc, dev, n, w, h, mu_s):
     arrays, cam = _scene(pkg, n, w, h, 0, seed=n, mu_s=mu_s)
     ref = oracle_forward(orc, arrays, cam, degree=0)
