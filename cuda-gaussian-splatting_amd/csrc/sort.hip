@@ -20,7 +20,6 @@ namespace {
 constexpr int RADIX = 256;
 constexpr int IPT = 16;                           // items per thread
 constexpr int CHUNK = CUGS_BLOCK * IPT;           // 4096 items per workgroup
-constexpr int WAVE_ITEMS = CUGS_WAVE * IPT;       // 1024 contiguous items per wave
 constexpr int FILL_CHUNK = CUGS_BLOCK;            // Gaussians per workgroup in scan/fill (one per thread)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -30,16 +29,17 @@ inline uint32_t nblocks_for(int64_t count, int chunk) { return (uint32_t)((count
 // scanned block sums, pair total) and read by cugs_sort_pairs; the pair-level one can only be sized
 // once the pair count is known.
 struct SortWsN {
-    unsigned long long* total;   // [0] pair total (u64), dword 4: zero-pair counter (quirk Q12)
+    unsigned long long* total;   // [0] pair total (u64); dwords 4-5: zero-pair counter (quirk Q12) and its snapshot
     uint32_t* dkey[2];           // depth bits, ping-pong              [n]
     uint32_t* dval[2];           // Gaussian index, ping-pong          [n]
+    int4* rect[2];               // {x0, y0, w | h << 16, tiles_touched} per Gaussian: [0] input order, [1] depth order
     uint32_t* tot;               // [RADIX]
     uint32_t* blocksum;          // per FILL_CHUNK block pair counts   [nfill + 2]
     uint32_t* hist;              // [RADIX][nblk_n] digit-major
     size_t bytes;
 };
 struct SortWsP {
-    uint32_t* ptile[2];          // tile id per pair, ping-pong        [P]
+    void* ptile[2];              // tile id per pair (u16 when the tile count allows, else u32), ping-pong [P]
     uint32_t* pidx[2];           // Gaussian index per pair            [P]
     uint32_t* hist;              // [RADIX][nblk_p]
     size_t bytes;
@@ -60,6 +60,7 @@ SortWsN carve_n(void* base, int64_t n) {
     w.total = c.take<unsigned long long>(32);
     for (int i = 0; i < 2; ++i) w.dkey[i] = c.take<uint32_t>((size_t)n);
     for (int i = 0; i < 2; ++i) w.dval[i] = c.take<uint32_t>((size_t)n);
+    for (int i = 0; i < 2; ++i) w.rect[i] = c.take<int4>((size_t)n);
     w.tot = c.take<uint32_t>(RADIX);
     w.blocksum = c.take<uint32_t>((size_t)nblocks_for(n, FILL_CHUNK) + 2);
     w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, CHUNK) + 1));
@@ -69,7 +70,7 @@ SortWsN carve_n(void* base, int64_t n) {
 SortWsP carve_p(void* base, int64_t pairs) {
     Carver c{static_cast<char*>(base)};
     SortWsP w;
-    for (int i = 0; i < 2; ++i) w.ptile[i] = c.take<uint32_t>((size_t)pairs);
+    for (int i = 0; i < 2; ++i) w.ptile[i] = c.take<uint32_t>((size_t)pairs);     // sized for the u32 case
     for (int i = 0; i < 2; ++i) w.pidx[i] = c.take<uint32_t>((size_t)pairs);
     w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(pairs, CHUNK) + 1));
     w.bytes = c.off;
@@ -89,16 +90,22 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
-// Exclusive scan of one value per thread over a 256-thread workgroup; *total = workgroup sum.
-// s_tmp: 4 dwords of LDS.  Contains two barriers.
+// Exclusive scan of one value per thread over a workgroup of NW waves; *total = workgroup sum.
+// s_tmp: NW dwords of LDS.  Contains two barriers.
+template <int NW = 4>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_tmp, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = wave_inclusive_scan(v);
     if (lane == 63) s_tmp[wave] = inc;
     __syncthreads();
-    uint32_t w0 = s_tmp[0], w1 = s_tmp[1], w2 = s_tmp[2], w3 = s_tmp[3];
-    uint32_t base = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
-    if (total) *total = w0 + w1 + w2 + w3;
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const uint32_t t = s_tmp[w];
+        base += (w < wave) ? t : 0u;
+        sum += t;
+    }
+    if (total) *total = sum;
     __syncthreads();
     return base + inc - v;
 }
@@ -108,52 +115,73 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 // nothing for it and its reserved slots keep the zero-initialised (key 0, value 0) pairs
 // (sorting.cu:166-167), which sort to the front of tile 0.  Reproduced here by giving such a
 // Gaussian the depth key 0 (its pairs are emitted first) and emitting (tile 0, Gaussian 0).
-__device__ __forceinline__ bool fills_nothing(const float* __restrict__ means_2d, int radius, uint32_t idx,
-                                              int img_w, int img_h, int ntx, int nty) {
-    if (radius <= 0) return true;                                   // sorting.cu:44-45
-    const TileRect tr = tile_rect_of(means_2d[idx * 2 + 0], means_2d[idx * 2 + 1], radius, img_w, img_h,
-                                     ntx, nty);
-    return tr.x1 <= tr.x0 || tr.y1 <= tr.y0;
-}
-
-__global__ __launch_bounds__(CUGS_BLOCK) void k_depth_keys(uint32_t n, const float* __restrict__ depths,
-                                                           const float* __restrict__ means_2d,
-                                                           const int32_t* __restrict__ radii,
-                                                           const int32_t* __restrict__ tiles, int img_w,
-                                                           int img_h, int ntx, int nty,
-                                                           uint32_t* __restrict__ keys) {
+//
+// One sequential read of the projection outputs produces the depth key and a 16-byte tile-rectangle
+// record per Gaussian, so that the depth-ordered stages gather ONE record per Gaussian instead of
+// tiles_touched, radius and mean separately (random 4-8 byte gathers were what bounded k_fill_pairs).
+__global__ __launch_bounds__(CUGS_BLOCK) void k_depth_keys_rect(uint32_t n, const float* __restrict__ depths,
+                                                                const float* __restrict__ means_2d,
+                                                                const int32_t* __restrict__ radii,
+                                                                const int32_t* __restrict__ tiles, int img_w,
+                                                                int img_h, int ntx, int nty,
+                                                                uint32_t* __restrict__ keys,
+                                                                int4* __restrict__ rect) {
     const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t key = __float_as_uint(depths[i]);
-    if (tiles[i] > 0 && fills_nothing(means_2d, radii[i], i, img_w, img_h, ntx, nty)) key = 0u;
+    const int t = tiles[i];
+    int x0 = 0, y0 = 0, w = 0, h = 0;             // w x h = pairs the reference's loops would write
+    if (t > 0) {
+        const int radius = radii[i];
+        if (radius > 0) {                                                // sorting.cu:44-45
+            const TileRect tr = tile_rect_of(means_2d[i * 2 + 0], means_2d[i * 2 + 1], radius, img_w, img_h, ntx, nty);
+            if (tr.x1 > tr.x0 && tr.y1 > tr.y0) { x0 = tr.x0; y0 = tr.y0; w = tr.x1 - tr.x0; h = tr.y1 - tr.y0; }
+        }
+        if (w == 0) key = 0u;                                            // fills nothing: Q12
+    }
     keys[i] = key;
+    rect[i] = make_int4(x0, y0, w | (h << 16), t > 0 ? t : 0);
 }
 
-// ------------------------------------------------------------------------------------
-// One radix pass = hist + row scan + scatter.  SRC_DEPTH: first pass of the depth sort, which
-// generates the Gaussian index on the fly instead of reading a value array.
-// ------------------------------------------------------------------------------------
-template <bool SRC_DEPTH>
-__device__ __forceinline__ uint32_t load_key(const uint32_t* __restrict__ keys, uint32_t i) {
-    return keys[i];
-}
-
-template <bool SRC_DEPTH>
-__global__ __launch_bounds__(CUGS_BLOCK) void k_radix_hist(const uint32_t* __restrict__ keys,
-                                                           uint32_t count, int shift, uint32_t mask,
-                                                           uint32_t* __restrict__ hist, uint32_t nblk) {
+// ctl: when given, block 0 hands the Q12 counter k_fill_pairs has finished adding to (ctl[0]) over to
+// k_tile_ranges (ctl[1]) and re-arms it, so that cugs_sort_pairs may be repeated on one count.
+template <typename K, int NT>
+__global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, uint32_t count, int shift,
+                                                   uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
+                                                   uint32_t* __restrict__ ctl) {
+    constexpr int PER = CHUNK / NT;                           // consecutive keys per thread (order is irrelevant here)
+    constexpr int NV = PER * (int)sizeof(K) / 16;             // ... fetched as 16-byte loads
+    constexpr int KPV = 16 / (int)sizeof(K);
+    static_assert(NV >= 1 && NV * KPV == PER, "whole 16-byte loads per thread");
     __shared__ uint32_t s_cnt[RADIX];
-    s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < RADIX) s_cnt[threadIdx.x] = 0;
+    if (ctl && blockIdx.x == 0 && threadIdx.x == 0) { ctl[1] = ctl[0]; ctl[0] = 0u; }
     __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t wbase = blockIdx.x * CHUNK + wave * WAVE_ITEMS;
+    const uint32_t bbase = blockIdx.x * CHUNK;
+    if (bbase + CHUNK <= count) {
+        const uint4* src = reinterpret_cast<const uint4*>(keys + bbase + threadIdx.x * PER);
+        uint4 q[NV];
 #pragma unroll
-    for (int r = 0; r < IPT; ++r) {
-        uint32_t i = wbase + r * CUGS_WAVE + lane;
-        if (i < count) atomicAdd(&s_cnt[(load_key<SRC_DEPTH>(keys, i) >> shift) & mask], 1u);
+        for (int v = 0; v < NV; ++v) q[v] = src[v];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const uint32_t wds[4] = {q[v].x, q[v].y, q[v].z, q[v].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (sizeof(K) == 4) {
+                    atomicAdd(&s_cnt[(wds[c] >> shift) & mask], 1u);
+                } else {
+                    atomicAdd(&s_cnt[((wds[c] & 0xFFFFu) >> shift) & mask], 1u);
+                    atomicAdd(&s_cnt[((wds[c] >> 16) >> shift) & mask], 1u);
+                }
+            }
+        }
+    } else {
+        for (uint32_t i = bbase + threadIdx.x; i < count; i += NT)
+            atomicAdd(&s_cnt[((uint32_t)keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
+    if (threadIdx.x < RADIX) hist[threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
 }
 
 // Block d: exclusive scan of row d of hist (in place); tot[d] = row sum.
@@ -179,59 +207,76 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(uint32_t* __rest
 // base in LDS.  The (key, value) pairs are first placed at their position in the workgroup's LOCALLY
 // sorted order in LDS and then streamed out, so that consecutive lanes write consecutive global
 // addresses inside each digit's run (4 B items scattered straight to 128-256 buckets cost ~2x).
-template <bool SRC_DEPTH>
-__global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scatter(
-    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count,
-    int shift, uint32_t mask, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ tot,
-    uint32_t nblk, uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-    __shared__ uint32_t s_lbase[4][RADIX];     // per (wave, digit): count, then running LOCAL position
+// IOTA: first pass of the depth sort, which generates the Gaussian index instead of reading a value
+// array.  NB: digit width (the match-any needs one ballot per digit bit).  NT: threads per workgroup -
+// 256 for the pair-level passes (thousands of workgroups), 1024 for the depth sort, whose 4096-item
+// chunks are too few to fill the chip with 4 waves each.
+template <typename K, bool IOTA, int NB, int NT>
+__global__ __launch_bounds__(NT) void k_radix_scatter(
+    const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count,
+    int shift, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ tot,
+    uint32_t nblk, K* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    constexpr uint32_t mask = (1u << NB) - 1u;
+    constexpr int NW = NT / CUGS_WAVE;                    // waves
+    constexpr int PER = CHUNK / NT;                       // items per thread
+    constexpr int SLICE = CUGS_WAVE * PER;                // contiguous items per wave
+    __shared__ uint32_t s_lbase[NW][RADIX];    // per (wave, digit): count, then running LOCAL position
     __shared__ uint32_t s_lstart[RADIX];       // first local position of digit d
     __shared__ uint32_t s_gbase[RADIX];        // first global position of this workgroup's digit-d run
-    __shared__ uint32_t s_key[CHUNK];
+    __shared__ K s_key[CHUNK];
     __shared__ uint32_t s_val[CHUNK];
-    __shared__ uint32_t s_tmp[4];
+    __shared__ uint32_t s_tmp[NW];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t bbase = blockIdx.x * CHUNK;
-    const uint32_t wbase = bbase + wave * WAVE_ITEMS;
+    const uint32_t wbase = bbase + wave * SLICE;
     const uint32_t count_blk = min((uint32_t)CHUNK, count - bbase);
 
-#pragma unroll
-    for (int w = 0; w < 4; ++w) s_lbase[w][tid] = 0;
+    for (uint32_t e = tid; e < NW * RADIX; e += NT) (&s_lbase[0][0])[e] = 0;
     __syncthreads();
 
-    uint32_t k[IPT], v[IPT];
+    uint32_t k[PER], v[PER];
 #pragma unroll
-    for (int r = 0; r < IPT; ++r) {
+    for (int r = 0; r < PER; ++r) {
         uint32_t i = wbase + r * CUGS_WAVE + lane;
         bool ok = i < count;
-        k[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
-        v[r] = ok ? (SRC_DEPTH ? i : vals_in[i]) : 0u;
+        k[r] = ok ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
+        v[r] = ok ? (IOTA ? i : vals_in[i]) : 0u;
         if (ok) atomicAdd(&s_lbase[wave][(k[r] >> shift) & mask], 1u);
     }
     __syncthreads();
 
-    {   // digit d = tid
-        const uint32_t c0 = s_lbase[0][tid], c1 = s_lbase[1][tid], c2 = s_lbase[2][tid], c3 = s_lbase[3][tid];
-        const uint32_t dig_base = block_exclusive_scan(tot[tid], s_tmp, nullptr);            // global digit start
-        const uint32_t lstart = block_exclusive_scan(c0 + c1 + c2 + c3, s_tmp, nullptr);     // local digit start
-        s_gbase[tid] = dig_base + hist[tid * nblk + blockIdx.x];
-        s_lstart[tid] = lstart;
-        s_lbase[0][tid] = lstart;
-        s_lbase[1][tid] = lstart + c0;
-        s_lbase[2][tid] = lstart + c0 + c1;
-        s_lbase[3][tid] = lstart + c0 + c1 + c2;
+    {   // digit d = tid (threads beyond the radix only take part in the barriers)
+        const bool dig = tid < RADIX;
+        uint32_t cnt = 0;
+        if (dig) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) cnt += s_lbase[w][tid];
+        }
+        const uint32_t dig_base = block_exclusive_scan<NW>(dig ? tot[tid] : 0u, s_tmp, nullptr);   // global digit start
+        const uint32_t lstart = block_exclusive_scan<NW>(cnt, s_tmp, nullptr);                     // local digit start
+        if (dig) {
+            s_gbase[tid] = dig_base + hist[tid * nblk + blockIdx.x];
+            s_lstart[tid] = lstart;
+            uint32_t run = lstart;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t c = s_lbase[w][tid];
+                s_lbase[w][tid] = run;
+                run += c;
+            }
+        }
     }
     __syncthreads();
 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int r = 0; r < IPT; ++r) {
+    for (int r = 0; r < PER; ++r) {
         const uint32_t i = wbase + r * CUGS_WAVE + lane;
         const bool ok = i < count;
         const uint32_t d = (k[r] >> shift) & mask;
         unsigned long long peers = __ballot(ok);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long m = __ballot(bit);
             peers &= bit ? m : ~m;
@@ -239,7 +284,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scatter(
         if (ok) {
             const uint32_t base = s_lbase[wave][d];
             const uint32_t pos = base + __popcll(peers & lt_mask);
-            s_key[pos] = k[r];
+            s_key[pos] = (K)k[r];
             s_val[pos] = v[r];
             if ((peers >> lane) == 1ull) s_lbase[wave][d] = base + __popcll(peers);
         }
@@ -247,11 +292,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scatter(
     __syncthreads();
 
 #pragma unroll
-    for (int r = 0; r < IPT; ++r) {
-        const uint32_t j = r * CUGS_BLOCK + tid;
+    for (int r = 0; r < PER; ++r) {
+        const uint32_t j = r * NT + tid;
         if (j < count_blk) {
-            const uint32_t key = s_key[j];
-            const uint32_t d = (key >> shift) & mask;
+            const K key = s_key[j];
+            const uint32_t d = ((uint32_t)key >> shift) & mask;
             const uint32_t dst = s_gbase[d] + (j - s_lstart[d]);
             keys_out[dst] = key;
             vals_out[dst] = s_val[j];
@@ -264,105 +309,144 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scatter(
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_blocksums(uint32_t n,
                                                                const uint32_t* __restrict__ order,
-                                                               const int32_t* __restrict__ tiles,
+                                                               const int4* __restrict__ rect,
+                                                               int4* __restrict__ rect_sorted,
                                                                uint32_t* __restrict__ blocksum) {
     __shared__ uint32_t s_tmp[4];
     const uint32_t i = blockIdx.x * FILL_CHUNK + threadIdx.x;
-    const uint32_t acc = i < n ? (uint32_t)tiles[order[i]] : 0u;
+    uint32_t acc = 0u;
+    if (i < n) {
+        const int4 r = rect[order[i]];             // the one gather per Gaussian
+        rect_sorted[i] = r;
+        acc = (uint32_t)r.w;
+    }
     uint32_t total;
     block_exclusive_scan(acc, s_tmp, &total);
     if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
 }
 
 // Single workgroup: exclusive scan of blocksum[0..nb) in place; *total = the 64-bit grand total =
-// sum(tiles_touched), the reference's cumsum[-1].item() (sorting.cu:145-146).
+// sum(tiles_touched), the reference's cumsum[-1].item() (sorting.cu:145-146).  16 consecutive entries per
+// thread, so 4096 entries cost two barriers.  Also arms the Q12 counter (ctl[0] = 0).
 __global__ __launch_bounds__(CUGS_BLOCK) void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb,
-                                                               unsigned long long* __restrict__ total) {
+                                                               unsigned long long* __restrict__ total,
+                                                               uint32_t* __restrict__ ctl) {
     __shared__ uint32_t s_tmp[4];
+    constexpr int PER = 16;
     unsigned long long carry = 0;
-    for (uint32_t base = 0; base < nb; base += CUGS_BLOCK) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < nb ? blocksum[i] : 0u;
+    for (uint32_t base = 0; base < nb; base += CUGS_BLOCK * PER) {
+        const uint32_t i0 = base + threadIdx.x * PER;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) { v[e] = (i0 + e < nb) ? blocksum[i0 + e] : 0u; sum += v[e]; }
         uint32_t chunk_total;
-        uint32_t ex = block_exclusive_scan(v, s_tmp, &chunk_total);
-        if (i < nb) blocksum[i] = (uint32_t)carry + ex;     // valid whenever the total fits int32 (checked on the host)
+        uint32_t run = (uint32_t)carry + block_exclusive_scan(sum, s_tmp, &chunk_total);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            if (i0 + e < nb) blocksum[i0 + e] = run;      // valid whenever the total fits int32 (checked on the host)
+            run += v[e];
+        }
         carry += chunk_total;
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) { *total = carry; ctl[0] = 0u; }
 }
 
 // k_fill_sort_pairs (sorting.cu:30-72), walked in depth order; only the tile id and the index are
-// stored (the depth half of the key is implied by the order).  One Gaussian per thread computes
-// its rectangle and its offset (workgroup scan); the workgroup then emits its pairs COOPERATIVELY:
-// output position k is owned by lane k % 256, which finds the Gaussian by binary search over the
-// 256 offsets in LDS - consecutive lanes write consecutive pairs (fully coalesced), and a splat
-// covering thousands of tiles no longer serialises one thread.
+// stored (the depth half of the key is implied by the order).  One Gaussian per thread computes its
+// rectangle and its offset (workgroup scan); each wave then emits the pairs of its own 64 Gaussians
+// COOPERATIVELY, 256 output slots at a time: the Gaussians whose span starts inside the window stamp
+// their lane number at that slot, a running maximum over the window (4 consecutive slots per lane + a
+// wave scan) turns the stamps into an owner per slot, and the slots are then written lane-strided -
+// consecutive lanes write consecutive pairs, and a splat covering thousands of tiles does not
+// serialise one thread.  No workgroup barrier inside the loop.
+// Housekeeping shared out over the grid: the {0,0} ranges of untouched tiles (sorting.cu:216).
+template <typename K>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     uint32_t n, uint32_t total_pairs, const uint32_t* __restrict__ order,
-    const int32_t* __restrict__ tiles, const float* __restrict__ means_2d,
-    const int32_t* __restrict__ radii, int img_w, int img_h, int ntx, int nty,
-    const uint32_t* __restrict__ blocksum, uint32_t* __restrict__ ptile, uint32_t* __restrict__ pidx,
-    uint32_t* __restrict__ zero_pairs) {
+    const int4* __restrict__ rect_sorted, int ntx,
+    const uint32_t* __restrict__ blocksum, K* __restrict__ ptile, uint32_t* __restrict__ pidx,
+    uint32_t* __restrict__ zero_pairs, int32_t* __restrict__ tile_ranges, uint32_t range_dwords) {
+    constexpr int WIN = 4 * CUGS_WAVE;                               // output slots per wave iteration
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_off[CUGS_BLOCK + 1];
-    __shared__ uint32_t s_g[CUGS_BLOCK];
-    __shared__ int s_x0[CUGS_BLOCK], s_y0[CUGS_BLOCK], s_w[CUGS_BLOCK], s_cnt[CUGS_BLOCK];
-    const uint32_t tid = threadIdx.x;
+    __shared__ int4 s_info[CUGS_BLOCK];                              // {Gaussian, x0, y0, rect width}
+    __shared__ int s_cnt[CUGS_BLOCK];
+    __shared__ uint4 s_own[4][CUGS_WAVE];                            // per wave: owner lane of each window slot
+    for (uint32_t z = blockIdx.x * CUGS_BLOCK + threadIdx.x; z < range_dwords; z += gridDim.x * CUGS_BLOCK)
+        tile_ranges[z] = 0;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t i = blockIdx.x * FILL_CHUNK + tid;
     uint32_t g = 0, t = 0;
     int x0 = 0, y0 = 0, w = 0, real = 0;          // real = pairs the reference's loops would write
     if (i < n) {
         g = order[i];
-        t = (uint32_t)tiles[g];
-        if (t > 0) {
-            const int radius = radii[g];
-            if (radius > 0) {                                        // sorting.cu:44-45
-                const TileRect tr = tile_rect_of(means_2d[g * 2 + 0], means_2d[g * 2 + 1], radius, img_w, img_h,
-                                                 ntx, nty);
-                if (tr.x1 > tr.x0 && tr.y1 > tr.y0) {
-                    x0 = tr.x0; y0 = tr.y0; w = tr.x1 - tr.x0;
-                    real = w * (tr.y1 - tr.y0);
-                }
-            }
-            if ((uint32_t)real < t) atomicAdd(zero_pairs, t - (uint32_t)real);   // quirk Q12 slots (rare)
-        }
+        const int4 r = rect_sorted[i];
+        t = (uint32_t)r.w;
+        x0 = r.x; y0 = r.y; w = r.z & 0xFFFF;
+        real = w * (r.z >> 16);
+        if ((uint32_t)real < t) atomicAdd(zero_pairs, t - (uint32_t)real);       // quirk Q12 slots (rare)
     }
     uint32_t blk_total;
     const uint32_t off = block_exclusive_scan(t, s_tmp, &blk_total);
     s_off[tid] = off;
-    s_g[tid] = g; s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = w; s_cnt[tid] = real;
+    s_info[tid] = make_int4((int)g, x0, y0, w);
+    s_cnt[tid] = real;
     if (tid == 0) s_off[CUGS_BLOCK] = blk_total;
     __syncthreads();
 
     const uint32_t out_base = blocksum[blockIdx.x];
-    for (uint32_t k = tid; k < blk_total; k += CUGS_BLOCK) {
-        // largest j with s_off[j] <= k among entries with a non-empty span: upper_bound - 1
-        uint32_t lo = 0, hi = CUGS_BLOCK;                            // invariant: s_off[lo] <= k < s_off[hi]
+    const uint32_t wstart = s_off[wave * CUGS_WAVE], wend = s_off[wave * CUGS_WAVE + CUGS_WAVE];
+    uint4* own4 = s_own[wave];
+    const uint32_t* own = reinterpret_cast<const uint32_t*>(own4);
+    uint32_t carry = 0;                                              // owner of the slot before the window
+    for (uint32_t base = wstart; base < wend; base += WIN) {
+        own4[lane] = make_uint4(0u, 0u, 0u, 0u);
+        __builtin_amdgcn_wave_barrier();
+        if (t > 0 && off >= base && off - base < (uint32_t)WIN) reinterpret_cast<uint32_t*>(own4)[off - base] = lane;
+        __builtin_amdgcn_wave_barrier();
+        uint4 a = own4[lane];
+        a.y = max(a.x, a.y); a.z = max(a.y, a.z); a.w = max(a.z, a.w);
+        uint32_t inc = a.w;                                          // inclusive running maximum over lanes
 #pragma unroll
-        for (int step = 0; step < 8; ++step) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_off[mid] <= k) lo = mid; else hi = mid;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if ((int)lane >= d) inc = max(inc, o);
         }
-        const uint32_t local = k - s_off[lo];
-        uint32_t tile = 0u, idx = 0u;                                // slots the reference leaves at zero (Q12)
-        if ((int)local < s_cnt[lo]) {
-            const int ww = s_w[lo];
-            const int row = (int)local / ww;
-            tile = (uint32_t)((s_y0[lo] + row) * ntx + s_x0[lo] + ((int)local - row * ww));
-            idx = s_g[lo];
+        uint32_t pre = __shfl_up(inc, 1);
+        pre = max(lane == 0 ? 0u : pre, carry);
+        a.x = max(a.x, pre); a.y = max(a.y, pre); a.z = max(a.z, pre); a.w = max(a.w, pre);
+        carry = __shfl(a.w, 63);
+        own4[lane] = a;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t k = base + e * CUGS_WAVE + lane;
+            if (k < wend) {
+                const uint32_t j = wave * CUGS_WAVE + own[e * CUGS_WAVE + lane];
+                const uint32_t local = k - s_off[j];
+                uint32_t tile = 0u, idx = 0u;                        // slots the reference leaves at zero (Q12)
+                if ((int)local < s_cnt[j]) {
+                    const int4 info = s_info[j];
+                    const int row = (int)local / info.w;
+                    tile = (uint32_t)((info.z + row) * ntx + info.y + ((int)local - row * info.w));
+                    idx = (uint32_t)info.x;
+                }
+                const uint32_t dst = out_base + k;
+                if (dst < total_pairs) {                             // never write past the buffers
+                    ptile[dst] = (K)tile;
+                    pidx[dst] = idx;
+                }
+            }
         }
-        const uint32_t dst = out_base + k;
-        if (dst < total_pairs) {                                     // never write past the buffers
-            ptile[dst] = tile;
-            pidx[dst] = idx;
-        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 // k_compute_tile_ranges (sorting.cu:82-109) on the sorted tile ids; optionally rebuilds the
 // reference's sorted 64-bit keys (SortingOutput::gaussian_keys_sorted, sorting.hpp:20).
+template <typename K>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t total_pairs,
-                                                            const uint32_t* __restrict__ ptile,
+                                                            const K* __restrict__ ptile,
                                                             const int32_t* __restrict__ pidx,
                                                             const float* __restrict__ depths,
                                                             int32_t* __restrict__ tile_ranges,
@@ -386,18 +470,31 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t total_pairs
                                             : (((uint64_t)cur << 32) | (uint64_t)__float_as_uint(depths[pidx[i]]));
 }
 
-template <bool SRC_DEPTH>
-int radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t count, int shift, int bits,
-               uint32_t* hist, uint32_t* tot, uint32_t* kout, uint32_t* vout, hipStream_t st) {
+template <typename K, bool IOTA, int NT>
+int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, int shift, int bits, uint32_t* hist, uint32_t* tot,
+               K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st) {
     const uint32_t nblk = nblocks_for(count, CHUNK);
-    const uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL((k_radix_hist<SRC_DEPTH>), dim3(nblk), dim3(CUGS_BLOCK), 0, st, kin, count, shift,
-                       mask, hist, nblk);
-    CUGS_LAUNCH_CHECK();
+    if (!hist_done) {
+        hipLaunchKernelGGL((k_radix_hist<K, NT>), dim3(nblk), dim3(NT), 0, st, kin, count, shift,
+                           (1u << bits) - 1u, hist, nblk, ctl);
+        CUGS_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, hist, nblk, tot);
     CUGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_radix_scatter<SRC_DEPTH>), dim3(nblk), dim3(CUGS_BLOCK), 0, st, kin, vin, count,
-                       shift, mask, hist, tot, nblk, kout, vout);
+#define CUGS_SCATTER(NB)                                                                                          \
+    hipLaunchKernelGGL((k_radix_scatter<K, IOTA, NB, NT>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, shift, \
+                       hist, tot, nblk, kout, vout)
+    switch (bits) {
+        case 1: CUGS_SCATTER(1); break;
+        case 2: CUGS_SCATTER(2); break;
+        case 3: CUGS_SCATTER(3); break;
+        case 4: CUGS_SCATTER(4); break;
+        case 5: CUGS_SCATTER(5); break;
+        case 6: CUGS_SCATTER(6); break;
+        case 7: CUGS_SCATTER(7); break;
+        default: CUGS_SCATTER(8); break;
+    }
+#undef CUGS_SCATTER
     CUGS_LAUNCH_CHECK();
     return 0;
 }
@@ -406,6 +503,41 @@ int tile_bits(int tiles) {
     int b = 1;
     while ((1 << b) < tiles) ++b;
     return b;
+}
+
+// Steps (2b)-(4) of cugs_sort_pairs for one tile-id width.
+template <typename K>
+int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t up, const float* means_2d,
+                     const float* depths, const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                     int ntx, int nty, uint64_t* keys_sorted, int32_t* values_sorted, int32_t* tile_ranges,
+                     hipStream_t st) {
+    const int tiles = ntx * nty;
+    const uint32_t* order = ws.dval[1];                 // left there by cugs_sort_count_pairs
+    const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
+    uint32_t* ctl = reinterpret_cast<uint32_t*>(ws.total) + 4;        // [0] Q12 counter, [1] its snapshot
+    const int bits = tile_bits(tiles);
+    const int npass = (bits + 7) / 8;
+    const int per = (bits + npass - 1) / npass;
+    K* tk[2] = {static_cast<K*>(wp.ptile[0]), static_cast<K*>(wp.ptile[1])};
+    uint32_t* tv[2] = {wp.pidx[0], wp.pidx[1]};
+    uint32_t* vals_final = reinterpret_cast<uint32_t*>(values_sorted);
+    hipLaunchKernelGGL((k_fill_pairs<K>), dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, up, order, ws.rect[1], ntx,
+                       ws.blocksum, tk[0], tv[0], ctl, tile_ranges, (uint32_t)(2 * tiles));
+    CUGS_LAUNCH_CHECK();
+    int cur = 0, rc;
+    for (int p = 0; p < npass; ++p) {
+        const int shift = p * per;
+        const int b = (bits - shift) < per ? (bits - shift) : per;
+        uint32_t* vout = (p == npass - 1) ? vals_final : tv[cur ^ 1];
+        if ((rc = radix_pass<K, false, CUGS_BLOCK>(tk[cur], tv[cur], up, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, false,
+                                       p == 0 ? ctl : nullptr, st)))
+            return rc;
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL((k_tile_ranges<K>), dim3(nblocks_for(up, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, up, tk[cur],
+                       values_sorted, depths, tile_ranges, keys_sorted, ctl + 1);
+    CUGS_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -436,24 +568,26 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const flo
     if (workspace_bytes < ws.bytes) return CUGS_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
+    if (ntx > 32767 || nty > 32767) return CUGS_EOVERFLOW;          // rectangle extents travel as 16-bit halves
     const uint32_t un = (uint32_t)n;
 
     // (1) stable sort of the Gaussians by depth bits (positive floats order as unsigned ints)
-    hipLaunchKernelGGL(k_depth_keys, dim3(nblocks_for(n, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
-                       means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1]);
+    hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(n, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
+                       means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1], ws.rect[0]);
     CUGS_LAUNCH_CHECK();
     int rc;
-    if ((rc = radix_pass<true>(ws.dkey[1], nullptr, un, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], st))) return rc;
-    if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], st))) return rc;
-    if ((rc = radix_pass<false>(ws.dkey[1], ws.dval[1], un, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], st))) return rc;
-    if ((rc = radix_pass<false>(ws.dkey[0], ws.dval[0], un, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], st))) return rc;
+    if ((rc = radix_pass<uint32_t, true, 1024>(ws.dkey[1], nullptr, un, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[0], ws.dval[0], un, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[1], ws.dval[1], un, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[0], ws.dval[0], un, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
 
     // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
     const uint32_t nfill = nblocks_for(n, FILL_CHUNK);
-    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], tiles_touched,
+    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
                        ws.blocksum);
     CUGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(CUGS_BLOCK), 0, st, ws.blocksum, nfill, ws.total);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(CUGS_BLOCK), 0, st, ws.blocksum, nfill, ws.total,
+                       reinterpret_cast<uint32_t*>(ws.total) + 4);
     CUGS_LAUNCH_CHECK();
 
     unsigned long long host_total = 0;
@@ -475,41 +609,22 @@ extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* mean
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
     const int tiles = ntx * nty;
-    if (tiles > 0)   // untouched tiles stay {0,0} (sorting.cu:216)
-        CUGS_RETURN_IF_HIP(hipMemsetAsync(tile_ranges, 0, sizeof(int32_t) * 2 * (size_t)tiles, st));
-    if (n == 0 || total_pairs == 0 || tiles == 0) return 0;      // sorting.cu:133-139,154-160
+    if (n == 0 || total_pairs == 0 || tiles == 0) {              // sorting.cu:133-139,154-160
+        if (tiles > 0)   // every tile stays {0,0} (sorting.cu:216)
+            CUGS_RETURN_IF_HIP(hipMemsetAsync(tile_ranges, 0, sizeof(int32_t) * 2 * (size_t)tiles, st));
+        return 0;
+    }
     if (!means_2d || !depths || !radii || !tiles_touched || !values_sorted || !workspace || !pair_workspace)
         return CUGS_EINVAL;
     SortWsN ws = carve_n(workspace, n);
     SortWsP wp = carve_p(pair_workspace, total_pairs);
     if (workspace_bytes < ws.bytes || pair_workspace_bytes < wp.bytes) return CUGS_EWORKSPACE;
 
+    // (2b) pairs in depth order; (3) stable sort by tile id, last pass landing in values_sorted; (4) ranges
     const uint32_t un = (uint32_t)n, up = (uint32_t)total_pairs;
-    uint32_t* zero_pairs = reinterpret_cast<uint32_t*>(ws.total) + 4;
-    CUGS_RETURN_IF_HIP(hipMemsetAsync(zero_pairs, 0, sizeof(uint32_t), st));
-    const uint32_t* order = ws.dval[1];                 // left there by cugs_sort_count_pairs
-    const uint32_t nfill = nblocks_for(n, FILL_CHUNK);
-
-    // (2b) pairs in depth order; (3) stable sort by tile id, last pass landing in values_sorted
-    const int bits = tile_bits(tiles);
-    const int npass = (bits + 7) / 8;
-    const int per = (bits + npass - 1) / npass;
-    uint32_t* vals_final = reinterpret_cast<uint32_t*>(values_sorted);
-    uint32_t* tk[2] = {wp.ptile[0], wp.ptile[1]};
-    uint32_t* tv[2] = {wp.pidx[0], wp.pidx[1]};
-    hipLaunchKernelGGL(k_fill_pairs, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, up, order, tiles_touched,
-                       means_2d, radii, width, height, ntx, nty, ws.blocksum, tk[0], tv[0], zero_pairs);
-    CUGS_LAUNCH_CHECK();
-    int cur = 0, rc;
-    for (int p = 0; p < npass; ++p) {
-        const int shift = p * per;
-        const int b = (bits - shift) < per ? (bits - shift) : per;
-        uint32_t* vout = (p == npass - 1) ? vals_final : tv[cur ^ 1];
-        if ((rc = radix_pass<false>(tk[cur], tv[cur], up, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, st))) return rc;
-        cur ^= 1;
-    }
-    hipLaunchKernelGGL(k_tile_ranges, dim3(nblocks_for(total_pairs, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st,
-                       up, tk[cur], values_sorted, depths, tile_ranges, keys_sorted, zero_pairs);
-    CUGS_LAUNCH_CHECK();
-    return 0;
+    if (tile_bits(tiles) <= 16)
+        return sort_pairs_typed<uint16_t>(ws, wp, un, up, means_2d, depths, radii, tiles_touched, width, height, ntx,
+                                          nty, keys_sorted, values_sorted, tile_ranges, st);
+    return sort_pairs_typed<uint32_t>(ws, wp, un, up, means_2d, depths, radii, tiles_touched, width, height, ntx,
+                                      nty, keys_sorted, values_sorted, tile_ranges, st);
 }
