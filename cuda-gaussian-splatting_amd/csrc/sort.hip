@@ -150,30 +150,37 @@ __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, u
                                                    uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
                                                    uint32_t* __restrict__ ctl) {
     constexpr int PER = CHUNK / NT;                           // consecutive keys per thread (order is irrelevant here)
-    constexpr int NV = PER * (int)sizeof(K) / 16;             // ... fetched as 16-byte loads
-    constexpr int KPV = 16 / (int)sizeof(K);
-    static_assert(NV >= 1 && NV * KPV == PER, "whole 16-byte loads per thread");
+    constexpr int NWORDS = PER * (int)sizeof(K) / 4;          // ... fetched as dwords in 16- or 8-byte loads
+    static_assert(NWORDS >= 2 && NWORDS * 4 == PER * (int)sizeof(K), "whole 8-byte loads per thread");
     __shared__ uint32_t s_cnt[RADIX];
     if (threadIdx.x < RADIX) s_cnt[threadIdx.x] = 0;
     if (ctl && blockIdx.x == 0 && threadIdx.x == 0) { ctl[1] = ctl[0]; ctl[0] = 0u; }
     __syncthreads();
     const uint32_t bbase = blockIdx.x * CHUNK;
     if (bbase + CHUNK <= count) {
-        const uint4* src = reinterpret_cast<const uint4*>(keys + bbase + threadIdx.x * PER);
-        uint4 q[NV];
+        uint32_t wds[NWORDS];
+        if constexpr (NWORDS % 4 == 0) {
+            const uint4* src = reinterpret_cast<const uint4*>(keys + bbase + threadIdx.x * PER);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) q[v] = src[v];
+            for (int v = 0; v < NWORDS / 4; ++v) {
+                const uint4 q = src[v];
+                wds[4 * v] = q.x; wds[4 * v + 1] = q.y; wds[4 * v + 2] = q.z; wds[4 * v + 3] = q.w;
+            }
+        } else {
+            const uint2* src = reinterpret_cast<const uint2*>(keys + bbase + threadIdx.x * PER);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const uint32_t wds[4] = {q[v].x, q[v].y, q[v].z, q[v].w};
+            for (int v = 0; v < NWORDS / 2; ++v) {
+                const uint2 q = src[v];
+                wds[2 * v] = q.x; wds[2 * v + 1] = q.y;
+            }
+        }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (sizeof(K) == 4) {
-                    atomicAdd(&s_cnt[(wds[c] >> shift) & mask], 1u);
-                } else {
-                    atomicAdd(&s_cnt[((wds[c] & 0xFFFFu) >> shift) & mask], 1u);
-                    atomicAdd(&s_cnt[((wds[c] >> 16) >> shift) & mask], 1u);
-                }
+        for (int c = 0; c < NWORDS; ++c) {
+            if (sizeof(K) == 4) {
+                atomicAdd(&s_cnt[(wds[c] >> shift) & mask], 1u);
+            } else {
+                atomicAdd(&s_cnt[((wds[c] & 0xFFFFu) >> shift) & mask], 1u);
+                atomicAdd(&s_cnt[((wds[c] >> 16) >> shift) & mask], 1u);
             }
         }
     } else {
@@ -529,9 +536,9 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         const int shift = p * per;
         const int b = (bits - shift) < per ? (bits - shift) : per;
         uint32_t* vout = (p == npass - 1) ? vals_final : tv[cur ^ 1];
-        if ((rc = radix_pass<K, false, CUGS_BLOCK>(tk[cur], tv[cur], up, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, false,
-                                       p == 0 ? ctl : nullptr, st)))
-            return rc;
+        rc = radix_pass<K, false, 512>(tk[cur], tv[cur], up, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, false,
+                                       p == 0 ? ctl : nullptr, st);   // 512 threads: measured best of 256/512/1024
+        if (rc) return rc;
         cur ^= 1;
     }
     hipLaunchKernelGGL((k_tile_ranges<K>), dim3(nblocks_for(up, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, up, tk[cur],
