@@ -50,26 +50,34 @@ def allreduce_gradients(grads: BackwardOutput, group: Optional[dist.ProcessGroup
 #     (= rank) order: the result is bit-identical on every rank, which an all-reduce does not promise.
 # --------------------------------------------------------------------------------------
 def collect_views(grads: BackwardOutput, gated_rgb: torch.Tensor, cam_center: torch.Tensor,
-                  group: Optional[dist.ProcessGroup] = None):
+                  group: Optional[dist.ProcessGroup] = None, need_centres: bool = True, defer_geometry: bool = False):
     """The collective half of the compact exchange (device-agnostic: RCCL on GPUs, gloo on CPU).
     The geometry gradients are all-reduced IN PLACE: as one collective when they are views of one flat
     buffer (render_backward(..., geom_flat=...)), else one collective each.
-    Returns (gated_views [V,N,3], centres [V,3])."""
+    Returns (gated_views [V,N,3], centres [V,3] or None, pending): with defer_geometry the geometry
+    all-reduce is still in flight on return and `pending` holds its work handles (wait_all them before
+    reading the geometry gradients), so the caller can rebuild the SH gradient underneath it."""
     n = gated_rgb.shape[0]
     if not dist.is_initialized():
-        return gated_rgb.reshape(1, n, 3), cam_center.reshape(1, 3)
+        return gated_rgb.reshape(1, n, 3), cam_center.reshape(1, 3), []
     world = dist.get_world_size(group)          # a 1-rank group still goes through the collectives
     # outputs are the rank-order concatenation along dim 0 (the shape both RCCL and gloo accept)
     views = torch.empty((world * n, 3), dtype=gated_rgb.dtype, device=gated_rgb.device)
-    centres = torch.empty((world * 3,), dtype=cam_center.dtype, device=cam_center.device)
     geom = [grads.geom_flat] if grads.geom_flat is not None else \
         [grads.dL_dpositions, grads.dL_dopacities, grads.dL_dscales, grads.dL_drotations]
-    works = [dist.all_gather_into_tensor(views, gated_rgb.reshape(n, 3).contiguous(), group=group, async_op=True)]
-    works += [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in geom]
-    works += [dist.all_gather_into_tensor(centres, cam_center.reshape(3).contiguous(), group=group, async_op=True)]
-    for w in works:
-        w.wait()
-    return views.view(world, n, 3), centres.view(world, 3)
+    # issue order = execution order on the communicator's stream: what the SH rebuild needs goes first
+    first = [dist.all_gather_into_tensor(views, gated_rgb.reshape(n, 3).contiguous(), group=group, async_op=True)]
+    centres = None
+    if need_centres:
+        centres = torch.empty((world * 3,), dtype=cam_center.dtype, device=cam_center.device)
+        first.append(dist.all_gather_into_tensor(centres, cam_center.reshape(3).contiguous(), group=group,
+                                                 async_op=True))
+    pending = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in geom]
+    wait_all(first)
+    if not defer_geometry:
+        wait_all(pending)
+        pending = []
+    return views.view(world, n, 3), (centres.view(world, 3) if centres is not None else None), pending
 
 
 def exchange_gradients(grads: BackwardOutput, gated_rgb: torch.Tensor, positions: torch.Tensor,
@@ -79,12 +87,15 @@ def exchange_gradients(grads: BackwardOutput, gated_rgb: torch.Tensor, positions
     render_backward(..., dL_drgb_gated_out=gated_rgb[, geom_flat=...]) (its dL_dsh_coeffs is None).
     On return the four geometry gradients hold the sums over all ranks' views (in place) and
     dL_dsh_coeffs is the summed SH gradient; dL_dmeans_2d stays per-view.  `all_cam_centers` ([V,3] host
-    values, if every rank knows every view's camera) avoids the device-to-host read of the gathered centres."""
+    values, if every rank knows every view's camera) saves the gather of the centres and its device-to-host
+    read.  The SH rebuild runs while the geometry all-reduce is still on the wire."""
     from .rasterizer import sh_backward_views
     cc = torch.as_tensor(cam_center, dtype=torch.float32, device=gated_rgb.device).reshape(3)
-    views, centres = collect_views(grads, gated_rgb, cc, group)
+    views, centres, pending = collect_views(grads, gated_rgb, cc, group, need_centres=all_cam_centers is None,
+                                            defer_geometry=True)
     host_centres = all_cam_centers if all_cam_centers is not None else centres.cpu().tolist()
     grads.dL_dsh_coeffs = sh_backward_views(active_sh_degree, positions, views, host_centres, num_coeffs)
+    wait_all(pending)
     return grads
 
 

@@ -31,7 +31,8 @@ def _worker(rank, world, port, q):
         g2 = pkg.BackwardOutput(mk(n, 3), mk(n, 4), mk(n, 3), mk(n, 1), None, mk(n, 2))
         gated, centre = mk(n, 3), mk(3)
         mine = dict(pos=g2.dL_dpositions.clone(), rot=g2.dL_drotations.clone(), gated=gated.clone(), centre=centre.clone())
-        gviews, centres = pkg.parallel.collect_views(g2, gated, centre)        # geometry reduced in place
+        gviews, centres, pending = pkg.parallel.collect_views(g2, gated, centre)   # geometry reduced in place
+        assert pending == []
         compact = dict(sum_pos=g2.dL_dpositions.numpy(), sum_rot=g2.dL_drotations.numpy(), views=gviews.numpy(),
                        centres=centres.numpy(), **{k: v.numpy() for k, v in mine.items()})
         # numpy: pickled by value (torch tensors would travel as shared-memory handles)
