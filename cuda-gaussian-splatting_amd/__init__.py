@@ -18,4 +18,5 @@ from .rasterizer import (evaluate_sh_backward_cuda, evaluate_sh_cuda, project_ba
 from .fused_adam import (AdamConfig, FusedAdam, ParamGroup, PositionLRConfig,  # noqa: F401
                          active_sh_degree_for_step, lr_defaults, position_lr)
 from .loss import combined_loss, combined_loss_and_grad, l1_loss, ssim, ssim_loss  # noqa: F401
+from .densification import DensificationConfig, DensificationController, DensificationStats  # noqa: F401
 from . import parallel, scene  # noqa: F401

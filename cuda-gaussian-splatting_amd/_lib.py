@@ -29,6 +29,13 @@ class AdamGroup(C.Structure):
                 ("n", C.c_int64), ("lr", C.c_float), ("reserved", C.c_float)]
 
 
+class DensifyArray(C.Structure):
+    """struct cugs_densify_array."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_floats", C.c_int32), ("mode", C.c_int32)]
+
+
+DENSIFY_COPY, DENSIFY_POSITIONS, DENSIFY_SCALES, DENSIFY_STATE = 0, 1, 2, 3
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -59,6 +66,11 @@ SIGNATURES = {
     "cugs_fused_adam_groups": (_I, [C.POINTER(AdamGroup), _I, _F, _F, _F, _F, _F, _P]),
     "cugs_loss_workspace_bytes": (C.c_size_t, [_I, _I]),
     "cugs_combined_loss": (_I, [_I, _I, _P, _P, _F, _I, _P, C.c_size_t, _P, _P, _P, _P]),
+    "cugs_densify_accumulate": (_I, [_L, _P, _P, _P, _P, _P, _P]),
+    "cugs_densify_classify": (_I, [_L, _P, _P, _P, _P, _P, _F, _F, _F, _I, _F, _F, _P, _P, _P]),
+    "cugs_densify_workspace_bytes": (C.c_size_t, [_L]),
+    "cugs_densify_plan": (_I, [_L, _P, _P, C.c_size_t, C.POINTER(C.c_int64), _P]),
+    "cugs_densify_apply": (_I, [_L, _L, _P, C.c_size_t, _P, _P, C.POINTER(DensifyArray), _I, _P]),
     "cugs_device_count": (_I, [C.POINTER(C.c_int)]),
 }
 

@@ -64,6 +64,23 @@ int main(int argc, char** argv) {
         save(d + "/out_dpos.bin", grads.dL_dpositions);
         save(d + "/out_dsh.bin", grads.dL_dsh_coeffs);
         save(d + "/out_positions_after_adam.bin", m.positions);
+        // N2 through the C++ host: statistics from this view, then one clone/split/prune cycle with the
+        // moments carried over; the noise comes from the test so the Python host can reproduce the result
+        {
+            cugs_hip::DensificationConfig dc;
+            dc.densify_from = 0; dc.densify_every = 5; dc.opacity_threshold = 0.05f; dc.grad_threshold = 2e-7f;
+            cugs_hip::DensificationController ctrl(dc, 6.0f);
+            ctrl.accumulate_gradients(grads.dL_dmeans_2d, out.radii);
+            auto noise = load(d + "/split_noise.bin", {2, n, 3});
+            auto stats = ctrl.densify(m, 5, noise, &opt);
+            save(d + "/out_densify_positions.bin", m.positions);
+            save(d + "/out_densify_sh.bin", m.sh_coeffs);
+            save(d + "/out_densify_scales.bin", m.scales);
+            printf("densify before=%d cloned=%d split=%d pruned=%d after=%d\n", stats.num_before, stats.num_cloned,
+                   stats.num_split, stats.num_pruned, stats.num_after);
+            opt.apply_gradients(cugs_hip::render_backward(g, cugs_hip::render(m, cam, st), m, cam, st));
+            opt.step();                                  // the optimizer still works on the resized model
+        }
         // the reference's TORCH_CHECK behaviour: a CPU tensor must be rejected with c10::Error
         bool threw = false;
         try { cugs_hip::evaluate_sh_cuda(1, torch::zeros({2, 3, 4}), torch::zeros({2, 3})); } catch (const c10::Error&) { threw = true; }

@@ -373,4 +373,117 @@ void FusedAdam::step() {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// N2: adaptive density control (optimizer/densification.cpp)
+// ---------------------------------------------------------------------------------------------
+bool DensificationController::should_densify(int step) const {             // densification.cpp:42-46
+    return step >= config_.densify_from && step <= config_.densify_until && step % config_.densify_every == 0;
+}
+bool DensificationController::should_reset_opacity(int step) const {       // :48-52
+    return config_.opacity_reset_every > 0 && step >= config_.densify_from && step % config_.opacity_reset_every == 0;
+}
+void DensificationController::reset_accumulators(int64_t n, const torch::Device& device) {   // :344-349
+    auto o = torch::TensorOptions().dtype(torch::kFloat32).device(device);
+    grad_accum_ = torch::zeros({n}, o); grad_count_ = torch::zeros({n}, o); max_radii_2d_ = torch::zeros({n}, o);
+}
+void DensificationController::accumulate_gradients(const torch::Tensor& dL_dmeans_2d, const torch::Tensor& radii) {
+    TORCH_CHECK(dL_dmeans_2d.is_cuda() && radii.is_cuda(), "accumulate_gradients: tensors must be on CUDA");
+    TORCH_CHECK(dL_dmeans_2d.dim() == 2 && dL_dmeans_2d.size(1) == 2, "dL_dmeans_2d must be [N, 2]");
+    const int64_t n = dL_dmeans_2d.size(0);
+    TORCH_CHECK(radii.numel() == n, "radii must be [N]");
+    if (!grad_accum_.defined() || grad_accum_.size(0) != n) reset_accumulators(n, dL_dmeans_2d.device());
+    auto g = dL_dmeans_2d.contiguous().to(torch::kFloat32);
+    auto r = radii.contiguous().to(torch::kInt32);
+    check(cugs_densify_accumulate(n, ptr<float>(g), ptr<int32_t>(r), ptr<float>(grad_accum_), ptr<float>(grad_count_),
+                                  ptr<float>(max_radii_2d_), stream_of(g)), "cugs_densify_accumulate");
+}
+void DensificationController::reset_opacity(ModelTensors& model) {          // :331-334
+    torch::NoGradGuard no_grad;
+    model.opacities.fill_(-4.59511985013459f);
+}
+DensificationStats DensificationController::densify(ModelTensors& model, int step, const torch::Tensor& noise_in,
+                                                    FusedAdam* optimizer) {
+    torch::NoGradGuard no_grad;
+    DensificationStats stats;
+    const int64_t n = model.positions.size(0);
+    stats.num_before = stats.num_after = static_cast<int>(n);
+    if (n == 0) return stats;
+    TORCH_CHECK(model.positions.is_cuda(), "densify: model must be on CUDA");
+    const auto dev = model.positions.device();
+    if (!grad_accum_.defined() || grad_accum_.size(0) != n) reset_accumulators(n, dev);
+    void* st = stream_of(model.positions);
+    auto scales_c = model.scales.contiguous(), opa_c = model.opacities.contiguous();
+    auto flags = torch::empty({n}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+    auto avg = torch::empty({n}, fopt(model.positions));
+    const float size_thr = config_.percent_dense * scene_extent_;           // :367, :394
+    const float ws_thr = 0.1f * scene_extent_;                              // :436
+    const int size_pruning = config_.opacity_reset_every > 0 && step > config_.opacity_reset_every;   // :415-416
+    check(cugs_densify_classify(n, ptr<float>(grad_accum_), ptr<float>(grad_count_), ptr<float>(max_radii_2d_),
+                                ptr<float>(scales_c), ptr<float>(opa_c), config_.grad_threshold, size_thr,
+                                config_.opacity_threshold, size_pruning, static_cast<float>(config_.max_screen_size),
+                                ws_thr, flags.data_ptr<uint8_t>(), ptr<float>(avg), st), "cugs_densify_classify");
+    if (config_.max_gaussians > 0) {                                        // :121-139, :184-209 (rare path: libtorch topk)
+        auto clone = flags.bitwise_and(1).to(torch::kBool);
+        int64_t num_clone = clone.sum().item<int64_t>();
+        const int64_t budget = config_.max_gaussians - n;
+        if (num_clone > budget) {
+            auto keep_clone = torch::zeros_like(clone);
+            if (budget > 0) keep_clone.index_fill_(0, std::get<1>(avg.masked_fill(~clone, -1.0f).topk(budget)), true);
+            clone = keep_clone;
+            num_clone = budget > 0 ? budget : 0;
+        }
+        auto split = flags.bitwise_right_shift(1).bitwise_and(1).to(torch::kBool);
+        const int64_t num_split = split.sum().item<int64_t>();
+        const int64_t sbudget = (config_.max_gaussians - (n + num_clone)) / 2;
+        if (num_split > sbudget) {
+            auto keep_split = torch::zeros_like(split);
+            if (sbudget > 0) keep_split.index_fill_(0, std::get<1>(avg.masked_fill(~split, -1.0f).topk(sbudget)), true);
+            split = keep_split;
+        }
+        flags = flags.bitwise_and(4).bitwise_or(clone.to(torch::kUInt8)).bitwise_or(split.to(torch::kUInt8).bitwise_left_shift(1)).contiguous();
+    }
+    auto ws = workspace(dev, cugs_densify_workspace_bytes(n), 3);
+    int64_t counts[4];
+    check(cugs_densify_plan(n, flags.data_ptr<uint8_t>(), ws.data_ptr(), ws.numel(), counts, st), "cugs_densify_plan");
+    const int64_t n_out = counts[3];
+    torch::Tensor noise = noise_in.defined() ? noise_in.contiguous().to(torch::kFloat32)
+                                             : (counts[2] > 0 ? torch::randn({2, n, 3}, fopt(model.positions))
+                                                              : torch::zeros({2, n, 3}, fopt(model.positions)));
+    TORCH_CHECK(noise.is_cuda() && noise.dim() == 3 && noise.size(0) == 2 && noise.size(1) == n && noise.size(2) == 3,
+                "noise must be [2, N, 3] on CUDA");
+    std::vector<torch::Tensor> srcs, dsts;
+    std::vector<cugs_densify_array> desc;
+    auto add = [&](const torch::Tensor& src, int mode) {
+        auto s = src.contiguous();
+        auto sizes = s.sizes().vec();
+        sizes[0] = n_out;
+        auto d = torch::empty(sizes, fopt(model.positions));
+        srcs.push_back(s); dsts.push_back(d);
+        desc.push_back(cugs_densify_array{s.data_ptr<float>(), d.data_ptr<float>(), static_cast<int32_t>(s.numel() / n), mode});
+        return d;
+    };
+    auto new_pos = add(model.positions, CUGS_DENSIFY_POSITIONS);
+    auto new_sh = add(model.sh_coeffs, CUGS_DENSIFY_COPY);
+    auto new_opa = add(model.opacities, CUGS_DENSIFY_COPY);
+    auto new_rot = add(model.rotations, CUGS_DENSIFY_COPY);
+    auto new_scl = add(model.scales, CUGS_DENSIFY_SCALES);
+    std::array<torch::Tensor, 5> nm, nv;
+    if (optimizer) for (int i = 0; i < 5; ++i) { nm[i] = add(optimizer->m_[i], CUGS_DENSIFY_STATE); nv[i] = add(optimizer->v_[i], CUGS_DENSIFY_STATE); }
+    if (n_out > 0)
+        check(cugs_densify_apply(n, n_out, ws.data_ptr(), ws.numel(), ptr<float>(noise), ptr<float>(scales_c), desc.data(),
+                                 static_cast<int>(desc.size()), st), "cugs_densify_apply");
+    model.positions = new_pos; model.sh_coeffs = new_sh; model.opacities = new_opa; model.rotations = new_rot; model.scales = new_scl;
+    if (optimizer) {
+        optimizer->params_ = {model.positions, model.sh_coeffs, model.opacities, model.scales, model.rotations};
+        optimizer->m_ = nm; optimizer->v_ = nv;
+        optimizer->zero_grad();
+    }
+    stats.num_cloned = static_cast<int>(counts[1]);
+    stats.num_split = static_cast<int>(counts[2]);
+    stats.num_pruned = static_cast<int>(n + counts[1] + 2 * counts[2] - n_out);   // :313-316
+    stats.num_after = static_cast<int>(n_out);
+    reset_accumulators(n_out, dev);                                               // :321
+    return stats;
+}
+
 }  // namespace cugs_hip

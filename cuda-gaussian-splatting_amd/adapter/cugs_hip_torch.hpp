@@ -94,10 +94,39 @@ public:
     float get_lr(int group) const { return lrs_[group]; }
     void step();
 private:
+    friend class DensificationController;      // carries m_/v_ through clone/split/prune
     std::array<torch::Tensor, 5> params_, m_, v_, grads_;
     std::array<float, 5> lrs_;
     AdamHyper h_;
     int step_count_ = 0;
+};
+
+// optimizer/densification.hpp:23-168 over csrc/densify.hip.  Same schedule, thresholds and
+// result order as the reference; the split noise is an argument ([2, N, 3] standard normal, drawn from the
+// device generator when undefined) and the VRAM guards are not mirrored.
+struct DensificationConfig {
+    int densify_from = 500, densify_until = 15000, densify_every = 100, opacity_reset_every = 3000;
+    float grad_threshold = 0.0002f, opacity_threshold = 0.005f, percent_dense = 0.01f;
+    int max_screen_size = 20, max_gaussians = 0;
+};
+struct DensificationStats { int num_cloned = 0, num_split = 0, num_pruned = 0, num_before = 0, num_after = 0; };
+class DensificationController {
+public:
+    DensificationController(const DensificationConfig& config, float scene_extent)
+        : config_(config), scene_extent_(scene_extent) {}
+    void accumulate_gradients(const torch::Tensor& dL_dmeans_2d, const torch::Tensor& radii);
+    bool should_densify(int step) const;
+    bool should_reset_opacity(int step) const;
+    // `optimizer` (optional): its parameter tensors are re-pointed at the new model and its moments carried over
+    // (survivors keep theirs, new Gaussians start at zero) instead of the reference's optimizer rebuild.
+    DensificationStats densify(ModelTensors& model, int step, const torch::Tensor& noise = {},
+                               FusedAdam* optimizer = nullptr);
+    void reset_opacity(ModelTensors& model);
+private:
+    void reset_accumulators(int64_t n, const torch::Device& device);
+    DensificationConfig config_;
+    float scene_extent_;
+    torch::Tensor grad_accum_, grad_count_, max_radii_2d_;
 };
 
 }  // namespace cugs_hip

@@ -198,6 +198,47 @@ int cugs_combined_loss(int width, int height, const float* rendered, const float
                        int window_size, void* workspace, size_t workspace_bytes, float* loss_out,
                        float* ssim_map, float* dL_dcolor, void* stream);
 
+/* ---- N2: adaptive density control (optimizer/densification.cpp) ------------------------------
+ * cugs_densify_accumulate: DensificationController::accumulate_gradients (densification.cpp:59-88), one
+ *   launch, no host sync: for radii > 0, grad_accum += ||dL_dmeans_2d||_2 and grad_count += 1; for every
+ *   Gaussian max_radii_2d = max(max_radii_2d, radii).  All three accumulators are float [n].
+ * cugs_densify_classify: compute_clone_mask / compute_split_mask / compute_keep_mask (:351-442) as one
+ *   byte per Gaussian: bit 0 clone candidate, bit 1 split candidate, bit 2 keep.  The thresholds are the
+ *   reference's float products (size = percent_dense * scene_extent, ws = 0.1f * scene_extent);
+ *   apply_size_pruning = (opacity_reset_every > 0 && step > opacity_reset_every); max_screen_size <= 0
+ *   disables the screen-size test.  avg_grad (nullable) receives grad_accum / max(grad_count, 1), the key
+ *   of the reference's max_gaussians top-k (:127-134).
+ * cugs_densify_plan: counts and orders the result of densify() (:116-325) for FINAL flags (bit 0 clone,
+ *   bit 1 split, bit 2 keep; the caller has applied any budget).  counts_host = {kept originals, clones,
+ *   splits, n_out = kept + clones + 2 * splits}; an original is kept iff bit 2 is set and bit 1 is not.
+ *   Blocks on a 32-byte read-back (the reference's sum().item() calls, :118,179).
+ * cugs_densify_apply: writes each array of the new model, n_out rows in the reference's final order
+ *   [kept originals | clones | first children | second children], each group in ascending parent index.
+ *   Modes: COPY (new rows copy the parent: sh, opacities, rotations), POSITIONS (children:
+ *   parent + noise[which][parent] * exp(scale - log 1.6), :253-262; noise is [2, n, 3] standard normal
+ *   supplied by the caller in place of the reference's torch::randn_like), SCALES (children: scale -
+ *   log 1.6), STATE (optimizer moments: survivors keep theirs, new rows are zero - the reference rebuilds
+ *   its optimizer instead, trainer.cpp:267-304).  `scales` is the OLD scales array [n, 3].
+ */
+enum { CUGS_DENSIFY_COPY = 0, CUGS_DENSIFY_POSITIONS = 1, CUGS_DENSIFY_SCALES = 2, CUGS_DENSIFY_STATE = 3 };
+typedef struct cugs_densify_array {
+    const float* src;     /* [n, row_floats] device */
+    float* dst;           /* [n_out, row_floats] device */
+    int32_t row_floats;
+    int32_t mode;         /* CUGS_DENSIFY_* */
+} cugs_densify_array;
+int cugs_densify_accumulate(int64_t n, const float* dL_dmeans_2d, const int32_t* radii, float* grad_accum,
+                            float* grad_count, float* max_radii_2d, void* stream);
+int cugs_densify_classify(int64_t n, const float* grad_accum, const float* grad_count, const float* max_radii_2d,
+                          const float* scales, const float* opacities, float grad_threshold, float size_threshold,
+                          float opacity_threshold, int apply_size_pruning, float max_screen_size,
+                          float ws_threshold, uint8_t* flags, float* avg_grad, void* stream);
+size_t cugs_densify_workspace_bytes(int64_t n);
+int cugs_densify_plan(int64_t n, const uint8_t* flags, void* workspace, size_t workspace_bytes,
+                      int64_t counts_host[4], void* stream);
+int cugs_densify_apply(int64_t n, int64_t n_out, const void* workspace, size_t workspace_bytes, const float* noise,
+                       const float* scales, const cugs_densify_array* arrays_host, int num_arrays, void* stream);
+
 /* Device properties the host side needs without linking the HIP runtime itself. */
 int cugs_device_count(int* count_host);
 

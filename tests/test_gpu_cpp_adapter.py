@@ -30,6 +30,8 @@ def test_cpp_adapter_matches_python_host(pkg, dev, tmp_path):
     camvec = np.array(list(abi.view) + [abi.fx, abi.fy, abi.cx, abi.cy] + list(abi.cam_center) + bg, np.float32)
     assert camvec.size == 26
     camvec.tofile(tmp_path / "camera.bin")
+    noise = torch.randn((2, n, 3), generator=torch.Generator().manual_seed(11))
+    noise.numpy().tofile(tmp_path / "split_noise.bin")
 
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUGS_ADAPTER_TRACE="1")
     res = subprocess.run([DRIVER, str(tmp_path), str(n), "16", str(w), str(h)], capture_output=True, text=True,
@@ -59,3 +61,19 @@ def test_cpp_adapter_matches_python_host(pkg, dev, tmp_path):
     # Adam's first step is ~lr * sign(g): elements whose gradient is at rounding-noise level may flip
     a, b = rd("out_positions_after_adam.bin", np.float32, (n, 3)), np_(model.positions)
     assert np.mean(np.abs(a - b) > 1e-6) < 1e-3
+    # N2 through the C++ host: same statistics, same noise -> same clone/split/prune as the Python host
+    ctrl = pkg.DensificationController(pkg.DensificationConfig(densify_from=0, densify_every=5, opacity_threshold=0.05,
+                                                               grad_threshold=2e-7), 6.0)
+    ctrl.accumulate_gradients(grads.dL_dmeans_2d, out.radii)
+    stats = ctrl.densify(model, 5, noise.to(dev), optimizer=opt)
+    line = [l for l in res.stdout.splitlines() if l.startswith("densify ")][0]
+    got = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in line.split()[1:]}
+    assert stats.num_cloned > 0 and stats.num_split > 0 and stats.num_pruned > stats.num_split
+    assert abs(got["after"] - stats.num_after) <= 2 and abs(got["cloned"] - stats.num_cloned) <= 2    # atomics-order noise
+    if got["after"] == stats.num_after and got["cloned"] == stats.num_cloned and got["split"] == stats.num_split:
+        m2 = stats.num_after
+        for name, shape, t in (("out_densify_positions.bin", (m2, 3), model.positions),
+                               ("out_densify_sh.bin", (m2, 3, 16), model.sh_coeffs),
+                               ("out_densify_scales.bin", (m2, 3), model.scales)):
+            a, b = rd(name, np.float32, shape), np_(t)
+            assert np.mean(np.abs(a - b) > 1e-5) < 2e-3, name
