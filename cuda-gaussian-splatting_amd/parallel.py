@@ -99,6 +99,20 @@ def exchange_gradients(grads: BackwardOutput, gated_rgb: torch.Tensor, positions
     return grads
 
 
+def allreduce_densify_stats(controller, group: Optional[dist.ProcessGroup] = None) -> None:
+    """SURVEY §8f N2 under data parallelism: every rank accumulates the densification statistics of its own
+    views (DensificationController.accumulate_gradients); before densify() the replicas must agree, so the
+    gradient-norm sums and observation counts are SUM-reduced (one collective over a [2, N] buffer) and the
+    screen radii MAX-reduced.  Equivalent to one controller having seen all views (densification.cpp:59-88)."""
+    if not dist.is_initialized() or controller.grad_accum_ is None:
+        return
+    both = torch.stack([controller.grad_accum_, controller.grad_count_])
+    w0 = dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    w1 = dist.all_reduce(controller.max_radii_2d_, op=dist.ReduceOp.MAX, group=group, async_op=True)
+    w0.wait(); w1.wait()
+    controller.grad_accum_, controller.grad_count_ = both[0].contiguous(), both[1].contiguous()
+
+
 def wait_all(works: Sequence) -> None:
     for w in works:
         w.wait()

@@ -35,6 +35,13 @@ def _worker(rank, world, port, q):
         assert pending == []
         compact = dict(sum_pos=g2.dL_dpositions.numpy(), sum_rot=g2.dL_drotations.numpy(), views=gviews.numpy(),
                        centres=centres.numpy(), **{k: v.numpy() for k, v in mine.items()})
+        # N2 statistics: per-rank accumulators (CPU tensors stand in for the device arrays) -> SUM / SUM / MAX
+        ctrl = pkg.DensificationController(pkg.DensificationConfig(), 5.0)
+        ctrl.grad_accum_, ctrl.grad_count_, ctrl.max_radii_2d_ = mk(n).abs(), torch.full((n,), float(rank + 1)), mk(n).abs() * 10
+        compact.update(acc=ctrl.grad_accum_.numpy().copy(), cnt=ctrl.grad_count_.numpy().copy(),
+                       rad=ctrl.max_radii_2d_.numpy().copy())
+        pkg.parallel.allreduce_densify_stats(ctrl)
+        compact.update(acc_out=ctrl.grad_accum_.numpy(), cnt_out=ctrl.grad_count_.numpy(), rad_out=ctrl.max_radii_2d_.numpy())
         # numpy: pickled by value (torch tensors would travel as shared-memory handles)
         q.put((rank, {k: v.numpy() for k, v in local.items()}, {k: v.numpy() for k, v in out.items()}, views, compact))
     finally:
@@ -63,6 +70,9 @@ def test_allreduce_gradients_world2_gloo():
         assert np.array_equal(c["centres"][0], c0["centre"]) and np.array_equal(c["centres"][1], c1["centre"])
         assert np.allclose(c["sum_pos"], c0["pos"] + c1["pos"]) and np.allclose(c["sum_rot"], c0["rot"] + c1["rot"])
     assert np.array_equal(c0["sum_pos"], c1["sum_pos"])
+    for c in (c0, c1):                                 # densification statistics agree on every replica
+        assert np.allclose(c["acc_out"], c0["acc"] + c1["acc"]) and np.array_equal(c["cnt_out"], c0["cnt"] + c1["cnt"])
+        assert np.array_equal(c["rad_out"], np.maximum(c0["rad"], c1["rad"]))
 
 
 def test_allreduce_is_noop_without_process_group(pkg):
