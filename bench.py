@@ -190,9 +190,12 @@ def main():
     ap.add_argument("--config", default="config3", choices=["config2", "config3", "config4"])
     ap.add_argument("--adam", action="store_true", help="include FusedAdam.step in the step (implied by config4)")
     ap.add_argument("--mu-s", type=float, default=None, help="override the log-scale mean (dense variant: -3.5)")
-    ap.add_argument("--exchange", default="compact", choices=["compact", "allreduce"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "compact", "allreduce"],
                     help="N>1 gradient exchange: compact = all-gather colour grads + all-reduce geometry grads "
-                         "(SH grads rebuilt locally); allreduce = SUM all-reduce of all five gradient tensors")
+                         "(SH grads rebuilt locally); allreduce = SUM all-reduce of all five gradient tensors; "
+                         "auto = time three steps of each before the warmup and keep the faster one")
+    ap.add_argument("--rehearse-calibration", action="store_true",
+                    help="run the auto exchange calibration even with a single rank (one-GPU rehearsal of the N>1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=1 << 20,
@@ -233,18 +236,39 @@ def main():
     # every rank knows every view's camera in this benchmark: no device-to-host read of the gathered centres
     all_centres = [pkg.scene.make_camera(wl.width, wl.height, view=r).camera_center().tolist() for r in range(world)]
 
+    exchange = {"mode": args.exchange if args.exchange != "auto" else "compact", "calibration_ms": None}
+
     def step(events):
         if forward_only:
             out = pkg.render(model, cam, settings)
             return out.total_pairs, out, None
         # under torch.distributed.run the exchange step always runs (also for a 1-rank rehearsal)
-        return timed_step(pkg, model, cam, settings, g, events, args.exchange, launched, opt, all_centres)
+        return timed_step(pkg, model, cam, settings, g, events, exchange["mode"], launched, opt, all_centres)
 
     def fence():
         torch.cuda.synchronize(dev)
         if launched:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
+
+    if args.exchange == "auto" and launched and (world > 1 or args.rehearse_calibration) and not forward_only:
+        # which exchange is faster depends on what RCCL makes of this node's xGMI links: measure, don't guess.
+        # Untimed, before the warmup; every rank takes the same decision (MAX over ranks of each time).
+        cal = []
+        for mode in ("compact", "allreduce"):
+            exchange["mode"] = mode
+            step([])
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step([])
+            fence()
+            cal.append((time.perf_counter() - t0) / 3 * 1e3)
+        t = torch.tensor(cal, dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        cal = [float(x) for x in t.tolist()]
+        exchange["mode"] = "compact" if cal[0] <= cal[1] else "allreduce"
+        exchange["calibration_ms"] = {"compact": round(cal[0], 4), "allreduce": round(cal[1], 4)}
 
     for _ in range(args.warmup):
         step([])
@@ -292,7 +316,8 @@ def main():
             "config": {"workload": wl.name + (" fwd only" if forward_only else " fwd+bwd") + (" +adam" if use_adam else ""),
                        "n_gaussians": wl.n, "width": wl.width, "height": wl.height, "sh_degree": wl.sh_degree,
                        "pairs": int(pairs), "mu_s": wl.mu_s, "views_per_step": n_gpus,
-                       "parallelism": f"dp{n_gpus}-views" + (f"+rccl-{args.exchange}" if launched else "")},
+                       "parallelism": f"dp{n_gpus}-views" + (f"+rccl-{exchange['mode']}" if launched else ""),
+                       "exchange_calibration_ms": exchange["calibration_ms"]},
             "roofline": roofline, "frame_roofline": frame,
             "stages_ms": {k: round(v, 4) for k, v in stages_ms.items()},
         }

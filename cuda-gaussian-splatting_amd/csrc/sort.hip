@@ -597,11 +597,13 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const flo
                        reinterpret_cast<uint32_t*>(ws.total) + 4);
     CUGS_LAUNCH_CHECK();
 
-    unsigned long long host_total = 0;
-    CUGS_RETURN_IF_HIP(hipMemcpyAsync(&host_total, ws.total, sizeof(host_total), hipMemcpyDeviceToHost, st));
+    // straight into the caller's variable: if that is pinned host memory the copy is one DMA, no staging
+    CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     CUGS_RETURN_IF_HIP(hipStreamSynchronize(st));
-    if (host_total > 2147483647ull) return CUGS_EOVERFLOW;   // the reference indexes pairs with int
-    *total_pairs_host = (int64_t)host_total;
+    if ((unsigned long long)*total_pairs_host > 2147483647ull) {   // the reference indexes pairs with int
+        *total_pairs_host = 0;
+        return CUGS_EOVERFLOW;
+    }
     return 0;
 }
 

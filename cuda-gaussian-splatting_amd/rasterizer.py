@@ -48,6 +48,17 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 _workspaces: Dict[tuple, torch.Tensor] = {}
 
 
+_pinned = {}
+
+
+def _pinned_total(device: torch.device) -> torch.Tensor:
+    t = _pinned.get(device)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64).pin_memory()
+        _pinned[device] = t
+    return t
+
+
 def _workspace(device: torch.device, nbytes: int, kind: str = "n") -> torch.Tensor:
     """Caller-owned scratch for the sort: grown on demand, reused across calls (the reference
     allocates CUB temp storage on every call, sorting.cu:198-200).  `kind`: "n" = the N-level buffer
@@ -149,14 +160,16 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
     i32 = dict(dtype=torch.int32, device=dev)
     tile_ranges = torch.empty((num_tiles, 2), **i32)
     st = _stream(dev)
-    total = C.c_int64(0)
+    total = _pinned_total(dev)                  # pinned: the 8-byte read-back is a single DMA
+    total[0] = 0
     tiles_c = tiles_touched.contiguous().to(torch.int32)
     means_c, depths_c, radii_c = means_2d.contiguous(), depths.contiguous(), radii.contiguous()
     ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n")
     if n > 0:
         check(lib.cugs_sort_count_pairs(n, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w),
-                                        int(img_h), _ptr(ws), ws.numel(), C.byref(total), st), "cugs_sort_count_pairs")
-    p = int(total.value)
+                                        int(img_h), _ptr(ws), ws.numel(),
+                                        C.cast(total.data_ptr(), C.POINTER(C.c_int64)), st), "cugs_sort_count_pairs")
+    p = int(total[0])
     keys = torch.empty((p if want_keys else 0,), dtype=torch.int64, device=dev)
     vals = torch.empty((p,), **i32)
     if num_tiles > 0:
