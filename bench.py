@@ -85,12 +85,18 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     proj = R.project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs,
                                cam, deg, settings.scale_modifier)
     ev[1].record()
-    srt = R.sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, cam.width, cam.height,
-                           want_keys=False)
+    # as in render(): the sort runs on the predicted pair count, the host reads the true one after queueing the blend
+    srt = R.sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, cam.width, cam.height,
+                                     want_keys=False)
     ev[2].record()
-    fwd = R.rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
-                              srt.gaussian_values_sorted, cam.width, cam.height, settings.background,
-                              packed=proj.packed)
+    blend = lambda s: R.rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
+                                          s.gaussian_values_sorted, cam.width, cam.height, settings.background,
+                                          packed=proj.packed)
+    fwd = blend(srt)
+    if isinstance(srt, R.PendingSort):
+        srt, valid = srt.finish()
+        if not valid:
+            fwd = blend(srt)
     ev[3].record()
     rb = R.rasterize_backward(g, proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
                               srt.gaussian_values_sorted, fwd.final_T, fwd.n_contrib, cam.width, cam.height,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "cugs_sort_pair_workspace_bytes": (C.c_size_t, [_L]),
     "cugs_sort_count_pairs": (_I, [_L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, C.POINTER(C.c_int64), _P]),
     "cugs_sort_pairs": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P, _P]),
+    "cugs_sort_pairs_predicted": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P,
+                                       C.POINTER(C.c_int64), _P]),
     "cugs_rasterize_forward": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
                                     _P, _P, _P, _P]),
     "cugs_rasterize_backward": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,

@@ -143,12 +143,23 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_depth_keys_rect(uint32_t n, cons
     rect[i] = make_int4(x0, y0, w | (h << 16), t > 0 ? t : 0);
 }
 
+// Pair-level kernels take their item count either exactly (dev_count == nullptr: `count`) or, for the
+// predicted-capacity path (cugs_sort_pairs_predicted), as min(*dev_count, count) with `count` the capacity
+// of the buffers - the host has not read the total yet.
+__device__ __forceinline__ uint32_t live_count(uint32_t count, const unsigned long long* __restrict__ dev_count) {
+    if (!dev_count) return count;
+    const unsigned long long t = *dev_count;
+    return t < (unsigned long long)count ? (uint32_t)t : count;
+}
+
 // ctl: when given, block 0 hands the Q12 counter k_fill_pairs has finished adding to (ctl[0]) over to
 // k_tile_ranges (ctl[1]) and re-arms it, so that cugs_sort_pairs may be repeated on one count.
 template <typename K, int NT>
-__global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, uint32_t count, int shift,
+__global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, uint32_t count_or_cap,
+                                                   const unsigned long long* __restrict__ dev_count, int shift,
                                                    uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
                                                    uint32_t* __restrict__ ctl) {
+    const uint32_t count = live_count(count_or_cap, dev_count);
     constexpr int PER = CHUNK / NT;                           // consecutive keys per thread (order is irrelevant here)
     constexpr int NWORDS = PER * (int)sizeof(K) / 4;          // ... fetched as dwords in 16- or 8-byte loads
     static_assert(NWORDS >= 2 && NWORDS * 4 == PER * (int)sizeof(K), "whole 8-byte loads per thread");
@@ -220,10 +231,12 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(uint32_t* __rest
 // chunks are too few to fill the chip with 4 waves each.
 template <typename K, bool IOTA, int NB, int NT>
 __global__ __launch_bounds__(NT) void k_radix_scatter(
-    const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count,
-    int shift, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ tot,
-    uint32_t nblk, K* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count_or_cap,
+    const unsigned long long* __restrict__ dev_count, int shift, const uint32_t* __restrict__ hist,
+    const uint32_t* __restrict__ tot, uint32_t nblk, K* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
     constexpr uint32_t mask = (1u << NB) - 1u;
+    const uint32_t count = live_count(count_or_cap, dev_count);
+    if (blockIdx.x * CHUNK >= count) return;              // chunks beyond the live items (capacity path): nothing to move
     constexpr int NW = NT / CUGS_WAVE;                    // waves
     constexpr int PER = CHUNK / NT;                       // items per thread
     constexpr int SLICE = CUGS_WAVE * PER;                // contiguous items per wave
@@ -369,8 +382,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_scan_blocksums(uint32_t* __restr
 // Housekeeping shared out over the grid: the {0,0} ranges of untouched tiles (sorting.cu:216).
 template <typename K>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
-    uint32_t n, uint32_t total_pairs, const uint32_t* __restrict__ order,
-    const int4* __restrict__ rect_sorted, int ntx,
+    uint32_t n, uint32_t pairs_or_cap, const unsigned long long* __restrict__ dev_count,
+    const uint32_t* __restrict__ order, const int4* __restrict__ rect_sorted, int ntx,
     const uint32_t* __restrict__ blocksum, K* __restrict__ ptile, uint32_t* __restrict__ pidx,
     uint32_t* __restrict__ zero_pairs, int32_t* __restrict__ tile_ranges, uint32_t range_dwords) {
     constexpr int WIN = 4 * CUGS_WAVE;                               // output slots per wave iteration
@@ -379,6 +392,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     __shared__ int4 s_info[CUGS_BLOCK];                              // {Gaussian, x0, y0, rect width}
     __shared__ int s_cnt[CUGS_BLOCK];
     __shared__ uint4 s_own[4][CUGS_WAVE];                            // per wave: owner lane of each window slot
+    const uint32_t total_pairs = live_count(pairs_or_cap, dev_count);
     for (uint32_t z = blockIdx.x * CUGS_BLOCK + threadIdx.x; z < range_dwords; z += gridDim.x * CUGS_BLOCK)
         tile_ranges[z] = 0;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -452,13 +466,15 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
 // k_compute_tile_ranges (sorting.cu:82-109) on the sorted tile ids; optionally rebuilds the
 // reference's sorted 64-bit keys (SortingOutput::gaussian_keys_sorted, sorting.hpp:20).
 template <typename K>
-__global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t total_pairs,
+__global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t pairs_or_cap,
+                                                            const unsigned long long* __restrict__ dev_count,
                                                             const K* __restrict__ ptile,
                                                             const int32_t* __restrict__ pidx,
                                                             const float* __restrict__ depths,
                                                             int32_t* __restrict__ tile_ranges,
                                                             uint64_t* __restrict__ keys_sorted,
                                                             const uint32_t* __restrict__ zero_pairs) {
+    const uint32_t total_pairs = live_count(pairs_or_cap, dev_count);
     const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
     if (i >= total_pairs) return;
     const uint32_t cur = ptile[i];
@@ -478,19 +494,19 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t total_pairs
 }
 
 template <typename K, bool IOTA, int NT>
-int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, int shift, int bits, uint32_t* hist, uint32_t* tot,
-               K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st) {
+int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned long long* dev_count, int shift, int bits,
+               uint32_t* hist, uint32_t* tot, K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st) {
     const uint32_t nblk = nblocks_for(count, CHUNK);
     if (!hist_done) {
-        hipLaunchKernelGGL((k_radix_hist<K, NT>), dim3(nblk), dim3(NT), 0, st, kin, count, shift,
+        hipLaunchKernelGGL((k_radix_hist<K, NT>), dim3(nblk), dim3(NT), 0, st, kin, count, dev_count, shift,
                            (1u << bits) - 1u, hist, nblk, ctl);
         CUGS_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, hist, nblk, tot);
     CUGS_LAUNCH_CHECK();
 #define CUGS_SCATTER(NB)                                                                                          \
-    hipLaunchKernelGGL((k_radix_scatter<K, IOTA, NB, NT>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, shift, \
-                       hist, tot, nblk, kout, vout)
+    hipLaunchKernelGGL((k_radix_scatter<K, IOTA, NB, NT>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count, \
+                       shift, hist, tot, nblk, kout, vout)
     switch (bits) {
         case 1: CUGS_SCATTER(1); break;
         case 2: CUGS_SCATTER(2); break;
@@ -517,7 +533,7 @@ template <typename K>
 int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t up, const float* means_2d,
                      const float* depths, const int32_t* radii, const int32_t* tiles_touched, int width, int height,
                      int ntx, int nty, uint64_t* keys_sorted, int32_t* values_sorted, int32_t* tile_ranges,
-                     hipStream_t st) {
+                     const unsigned long long* dev_count, hipStream_t st) {
     const int tiles = ntx * nty;
     const uint32_t* order = ws.dval[1];                 // left there by cugs_sort_count_pairs
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
@@ -528,7 +544,7 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
     K* tk[2] = {static_cast<K*>(wp.ptile[0]), static_cast<K*>(wp.ptile[1])};
     uint32_t* tv[2] = {wp.pidx[0], wp.pidx[1]};
     uint32_t* vals_final = reinterpret_cast<uint32_t*>(values_sorted);
-    hipLaunchKernelGGL((k_fill_pairs<K>), dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, up, order, ws.rect[1], ntx,
+    hipLaunchKernelGGL((k_fill_pairs<K>), dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, up, dev_count, order, ws.rect[1], ntx,
                        ws.blocksum, tk[0], tv[0], ctl, tile_ranges, (uint32_t)(2 * tiles));
     CUGS_LAUNCH_CHECK();
     int cur = 0, rc;
@@ -536,15 +552,44 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         const int shift = p * per;
         const int b = (bits - shift) < per ? (bits - shift) : per;
         uint32_t* vout = (p == npass - 1) ? vals_final : tv[cur ^ 1];
-        rc = radix_pass<K, false, 512>(tk[cur], tv[cur], up, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, false,
+        rc = radix_pass<K, false, 512>(tk[cur], tv[cur], up, dev_count, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, false,
                                        p == 0 ? ctl : nullptr, st);   // 512 threads: measured best of 256/512/1024
         if (rc) return rc;
         cur ^= 1;
     }
-    hipLaunchKernelGGL((k_tile_ranges<K>), dim3(nblocks_for(up, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, up, tk[cur],
+    hipLaunchKernelGGL((k_tile_ranges<K>), dim3(nblocks_for(up, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, up, dev_count, tk[cur],
                        values_sorted, depths, tile_ranges, keys_sorted, ctl + 1);
     CUGS_LAUNCH_CHECK();
     return 0;
+}
+
+// Steps (1)-(2a): everything that does not depend on the pair count.  Queued, never blocks.
+int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const float* depths, const int32_t* radii,
+                const int32_t* tiles_touched, int width, int height, int ntx, int nty, hipStream_t st) {
+    // (1) stable sort of the Gaussians by depth bits (positive floats order as unsigned ints)
+    hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
+                       means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1], ws.rect[0]);
+    CUGS_LAUNCH_CHECK();
+    int rc;
+    if ((rc = radix_pass<uint32_t, true, 1024>(ws.dkey[1], nullptr, un, nullptr, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[0], ws.dval[0], un, nullptr, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[1], ws.dval[1], un, nullptr, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+    // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
+    const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
+    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
+                       ws.blocksum);
+    CUGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(CUGS_BLOCK), 0, st, ws.blocksum, nfill, ws.total,
+                       reinterpret_cast<uint32_t*>(ws.total) + 4);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename... A>
+int sort_pairs_dispatch(int tiles, A... args) {
+    if (tile_bits(tiles) <= 16) return sort_pairs_typed<uint16_t>(args...);
+    return sort_pairs_typed<uint32_t>(args...);
 }
 
 }  // namespace
@@ -576,27 +621,8 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
     if (ntx > 32767 || nty > 32767) return CUGS_EOVERFLOW;          // rectangle extents travel as 16-bit halves
-    const uint32_t un = (uint32_t)n;
-
-    // (1) stable sort of the Gaussians by depth bits (positive floats order as unsigned ints)
-    hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(n, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
-                       means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1], ws.rect[0]);
-    CUGS_LAUNCH_CHECK();
-    int rc;
-    if ((rc = radix_pass<uint32_t, true, 1024>(ws.dkey[1], nullptr, un, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
-    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[0], ws.dval[0], un, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
-    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[1], ws.dval[1], un, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
-    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[0], ws.dval[0], un, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
-
-    // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
-    const uint32_t nfill = nblocks_for(n, FILL_CHUNK);
-    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
-                       ws.blocksum);
-    CUGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(CUGS_BLOCK), 0, st, ws.blocksum, nfill, ws.total,
-                       reinterpret_cast<uint32_t*>(ws.total) + 4);
-    CUGS_LAUNCH_CHECK();
-
+    int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st);
+    if (rc) return rc;
     // straight into the caller's variable: if that is pinned host memory the copy is one DMA, no staging
     CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     CUGS_RETURN_IF_HIP(hipStreamSynchronize(st));
@@ -630,10 +656,49 @@ extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* mean
     if (workspace_bytes < ws.bytes || pair_workspace_bytes < wp.bytes) return CUGS_EWORKSPACE;
 
     // (2b) pairs in depth order; (3) stable sort by tile id, last pass landing in values_sorted; (4) ranges
-    const uint32_t un = (uint32_t)n, up = (uint32_t)total_pairs;
-    if (tile_bits(tiles) <= 16)
-        return sort_pairs_typed<uint16_t>(ws, wp, un, up, means_2d, depths, radii, tiles_touched, width, height, ntx,
-                                          nty, keys_sorted, values_sorted, tile_ranges, st);
-    return sort_pairs_typed<uint32_t>(ws, wp, un, up, means_2d, depths, radii, tiles_touched, width, height, ntx,
-                                      nty, keys_sorted, values_sorted, tile_ranges, st);
+    return sort_pairs_dispatch(tiles, ws, wp, (uint32_t)n, (uint32_t)total_pairs, means_2d, depths, radii, tiles_touched,
+                               width, height, ntx, nty, keys_sorted, values_sorted, tile_ranges,
+                               static_cast<const unsigned long long*>(nullptr), st);
+}
+
+// The whole sort without a host round trip: the caller PREDICTS the pair count (`capacity`, e.g. the last
+// frame's count plus a margin), sizes pair_workspace / keys_sorted / values_sorted for it, and every
+// pair-level kernel takes the live count from device memory.  The 8-byte total is copied to
+// *total_pairs_host asynchronously (use pinned memory); once the stream (or an event recorded after this
+// call) has completed, the results are valid iff 0 <= *total_pairs_host <= capacity - otherwise call
+// cugs_sort_pairs with the now known count (the N-level workspace still holds the depth order).  The
+// ~45 us the device idles in cugs_sort_count_pairs + cugs_sort_pairs while the host reads the total
+// and launches the rest (3 % of a 1 M-Gaussian 1080p frame) disappear.
+extern "C" int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
+                                         const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                                         void* workspace, size_t workspace_bytes, void* pair_workspace,
+                                         size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                                         int32_t* tile_ranges, int64_t* total_pairs_host, void* stream) {
+    if (n < 0 || capacity < 0 || width < 0 || height < 0 || !tile_ranges || !total_pairs_host) return CUGS_EINVAL;
+    if (n > 2147483647ll || capacity > 2147483647ll) return CUGS_EOVERFLOW;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
+    const int tiles = ntx * nty;
+    if (ntx > 32767 || nty > 32767) return CUGS_EOVERFLOW;
+    *total_pairs_host = 0;
+    if (n == 0 || tiles == 0) {
+        if (tiles > 0) CUGS_RETURN_IF_HIP(hipMemsetAsync(tile_ranges, 0, sizeof(int32_t) * 2 * (size_t)tiles, st));
+        return 0;
+    }
+    if (!means_2d || !depths || !radii || !tiles_touched || !workspace) return CUGS_EINVAL;
+    SortWsN ws = carve_n(workspace, n);
+    if (workspace_bytes < ws.bytes) return CUGS_EWORKSPACE;
+    int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st);
+    if (rc) return rc;
+    CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (capacity == 0) {                                          // valid iff the total turns out to be 0
+        CUGS_RETURN_IF_HIP(hipMemsetAsync(tile_ranges, 0, sizeof(int32_t) * 2 * (size_t)tiles, st));
+        return 0;
+    }
+    if (!values_sorted || !pair_workspace) return CUGS_EINVAL;
+    SortWsP wp = carve_p(pair_workspace, capacity);
+    if (pair_workspace_bytes < wp.bytes) return CUGS_EWORKSPACE;
+    return sort_pairs_dispatch(tiles, ws, wp, (uint32_t)n, (uint32_t)capacity, means_2d, depths, radii, tiles_touched,
+                               width, height, ntx, nty, keys_sorted, values_sorted, tile_ranges,
+                               static_cast<const unsigned long long*>(ws.total), st);
 }

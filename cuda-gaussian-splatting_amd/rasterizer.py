@@ -181,6 +181,71 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
     return SortingOutput(keys, vals, tile_ranges, p)
 
 
+# --------------------------------------------------------------------------------------
+# Sort without the host round trip (cugs_sort_pairs_predicted): the pair count of the previous frame on a
+# device predicts this frame's; the host keeps launching (the forward blend) while the sort runs and reads
+# the true count afterwards.  A wrong prediction is detected then and the exact path is taken instead.
+# --------------------------------------------------------------------------------------
+_last_pairs = {}                    # device -> pair count of the last sort
+PREDICT_MARGIN = (1.03, 65536)      # capacity = last * 1.03 + 64 Ki
+
+
+class PendingSort:
+    """Result of sort_gaussians_predicted(): tile_ranges / gaussian_values_sorted may be handed to
+    rasterize_forward at once; finish() waits for the count and returns (SortingOutput, valid) - if not
+    valid the prediction was too small and everything launched on these buffers must be redone with the
+    returned (exact) SortingOutput."""
+
+    def __init__(self, args, keys, vals, tile_ranges, capacity, total, event):
+        self._args, self._keys, self._vals, self.tile_ranges = args, keys, vals, tile_ranges
+        self.capacity, self._total, self._event = capacity, total, event
+        self.gaussian_values_sorted = vals
+
+    def finish(self):
+        self._event.synchronize()
+        p = int(self._total[0])
+        means_2d, depths, radii, tiles, img_w, img_h, want_keys = self._args
+        _torch_check(0 <= p <= 2147483647, "pair count exceeds the reference's int indexing")
+        _last_pairs[means_2d.device] = p
+        if p <= self.capacity:
+            keys = self._keys[:p] if want_keys else self._keys
+            return SortingOutput(keys, self._vals[:p], self.tile_ranges, p), True
+        return sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys), False
+
+
+def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Tensor,
+                             tiles_touched: torch.Tensor, img_w: int, img_h: int, want_keys: bool = False):
+    """sort_gaussians with the pair count predicted from the previous call on this device.  Returns a
+    PendingSort, or (no prediction yet / empty input) a finished SortingOutput."""
+    dev = means_2d.device
+    n = int(means_2d.shape[0])
+    last = _last_pairs.get(dev)
+    ntx = (img_w + K_TILE_SIZE - 1) // K_TILE_SIZE
+    nty = (img_h + K_TILE_SIZE - 1) // K_TILE_SIZE
+    if last is None or n == 0 or ntx * nty == 0:
+        out = sort_gaussians(means_2d, depths, radii, tiles_touched, img_w, img_h, want_keys)
+        _last_pairs[dev] = out.total_pairs
+        return out
+    cap = min(int(last * PREDICT_MARGIN[0]) + PREDICT_MARGIN[1], 2147483647)
+    i32 = dict(dtype=torch.int32, device=dev)
+    tile_ranges = torch.empty((ntx * nty, 2), **i32)
+    keys = torch.empty((cap if want_keys else 0,), dtype=torch.int64, device=dev)
+    vals = torch.empty((cap,), **i32)
+    tiles_c = tiles_touched.contiguous().to(torch.int32)
+    means_c, depths_c, radii_c = means_2d.contiguous(), depths.contiguous(), radii.contiguous()
+    ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n")
+    wp = _workspace(dev, lib.cugs_sort_pair_workspace_bytes(cap), "p")
+    total = _pinned_total(dev)
+    check(lib.cugs_sort_pairs_predicted(n, cap, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w),
+                                        int(img_h), _ptr(ws), ws.numel(), _ptr(wp), wp.numel(),
+                                        _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals), _ptr(tile_ranges),
+                                        C.cast(total.data_ptr(), C.POINTER(C.c_int64)), _stream(dev)),
+          "cugs_sort_pairs_predicted")
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingSort((means_c, depths_c, radii_c, tiles_c, img_w, img_h, want_keys), keys, vals, tile_ranges, cap, total, ev)
+
+
 def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: torch.Tensor,
                       opacities: torch.Tensor, tile_ranges: torch.Tensor, gaussian_indices: torch.Tensor,
                       img_w: int, img_h: int, background: Sequence[float],
@@ -312,11 +377,16 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings) -
     active_degree = min(int(settings.active_sh_degree), model.max_sh_degree())
     proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs,
                              camera, active_degree, settings.scale_modifier)
-    srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, camera.width,
-                         camera.height, want_keys=False)
-    fwd = rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
-                            srt.gaussian_values_sorted, camera.width, camera.height, settings.background,
-                            packed=proj.packed)
+    blend = lambda s: rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
+                                        s.gaussian_values_sorted, camera.width, camera.height, settings.background,
+                                        packed=proj.packed)
+    srt = sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, camera.width,
+                                   camera.height, want_keys=False)
+    fwd = blend(srt)                                     # queued behind the sort; the host has not waited yet
+    if isinstance(srt, PendingSort):
+        srt, valid = srt.finish()
+        if not valid:                                    # prediction too small (e.g. right after densification)
+            fwd = blend(srt)
     return RenderOutput(fwd.color, fwd.final_T, fwd.n_contrib, proj.means_2d, proj.depths, proj.cov_2d_inv,
                         proj.radii, proj.rgb, proj.opacities_act, srt.gaussian_values_sorted, srt.tile_ranges,
                         packed=proj.packed, total_pairs=srt.total_pairs)

@@ -109,6 +109,19 @@ int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* means_2d, const
                     size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
                     int32_t* tile_ranges, void* stream);
 
+/* The whole sort (cugs_sort_count_pairs + cugs_sort_pairs) WITHOUT the host round trip: the caller predicts
+ * the pair count (`capacity`: e.g. the previous frame's count plus a margin) and sizes pair_workspace
+ * (cugs_sort_pair_workspace_bytes(capacity)), keys_sorted and values_sorted for it; the pair-level kernels take
+ * the live count from device memory.  The total is copied to *total_pairs_host asynchronously (pinned host
+ * memory recommended); once the stream has completed, the outputs are valid iff
+ * 0 <= *total_pairs_host <= capacity - otherwise call cugs_sort_pairs with the now known count (the N-level
+ * workspace still holds the depth order).  Never blocks. */
+int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
+                              const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                              void* workspace, size_t workspace_bytes, void* pair_workspace,
+                              size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                              int32_t* tile_ranges, int64_t* total_pairs_host, void* stream);
+
 /* ---- a6: rasterize_forward (forward.cu:180-240, kernel :48-174) ---------------------
  * out_color [H,W,3], out_final_T [H,W], out_n_contrib [H,W] i32.  `packed` may be NULL
  * (records are then gathered from the four reference-layout arrays). */

@@ -77,6 +77,42 @@ def test_sort_parity_bit_exact(pkg, orc, dev, n, w, h, mu_s):
     assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])                          # per-tile spans
 
 
+def test_sort_predicted_capacity_path(pkg, orc, dev):
+    """cugs_sort_pairs_predicted: same result as the exact two-call path when the capacity suffices (also with
+    keys and with spare capacity), a detectable miss when it does not, and a clean empty case."""
+    R = pkg.rasterizer
+    n, w, h = 30000, 640, 360
+    arrays, cam = _scene(pkg, n, w, h, 0, seed=5, mu_s=-4.2)
+    ref = oracle_forward(orc, arrays, cam, degree=0)
+    t = lambda k: torch.from_numpy(ref[k]).to(dev)
+    args = (t("means_2d"), t("depths"), t("radii"), t("tiles_touched"), w, h)
+    margin = R.PREDICT_MARGIN
+    try:
+        for last, mg, expect_valid in ((ref["total_pairs"], (1.0, 0), True),          # exact capacity
+                                       (ref["total_pairs"], (1.5, 4096), True),       # spare capacity
+                                       (ref["total_pairs"] - 1, (1.0, 0), False),     # one short: must be detected
+                                       (7, (1.0, 0), False)):
+            R._last_pairs[torch.device(dev)] = last
+            R.PREDICT_MARGIN = mg
+            pend = R.sort_gaussians_predicted(*args, want_keys=True)
+            assert isinstance(pend, R.PendingSort)
+            srt, valid = pend.finish()
+            assert valid == expect_valid and srt.total_pairs == ref["total_pairs"]
+            assert np.array_equal(np_(srt.gaussian_keys_sorted).view(np.uint64), ref["keys"])
+            assert np.array_equal(np_(srt.gaussian_values_sorted), ref["values"])
+            assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])
+            assert R._last_pairs[torch.device(dev)] == ref["total_pairs"]
+        # nothing visible: the predicted path must leave every tile {0,0} and report zero pairs
+        R._last_pairs[torch.device(dev)] = 1000
+        z = torch.zeros(50, dtype=torch.int32, device=dev)
+        pend = R.sort_gaussians_predicted(torch.zeros((50, 2), device=dev), torch.ones(50, device=dev), z, z, w, h)
+        srt, valid = pend.finish()
+        assert valid and srt.total_pairs == 0 and not bool(srt.tile_ranges.any()) and srt.gaussian_values_sorted.numel() == 0
+    finally:
+        R.PREDICT_MARGIN = margin
+        R._last_pairs.pop(torch.device(dev), None)
+
+
 def test_sort_equal_depth_ties_keep_index_order(pkg, orc, dev):
     """CUB's stability contract: equal (tile, depth) keys stay in ascending Gaussian index."""
     w, h, n = 128, 96, 4000
