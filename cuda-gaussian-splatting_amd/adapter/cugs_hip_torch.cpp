@@ -4,11 +4,13 @@
 #include "cugs_hip_torch.hpp"
 
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -257,10 +259,56 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     auto proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, camera,
                                   degree, settings.scale_modifier);
     if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] projected\n");
-    auto srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
+    // The sort runs on the pair count predicted from this device's previous frame (cugs_sort_pairs_predicted) and
+    // the forward blend is queued behind it before the host looks at the true count: no idle device while the
+    // host waits.  A prediction that was too small is detected afterwards and the exact path re-run.
+    static thread_local auto& last_pairs = *new std::map<int, int64_t>();
+    static thread_local auto& pinned = *new std::map<int, torch::Tensor>();
+    const int dev_index = model.positions.device().index();
+    auto blend = [&](const SortingOutput& s) {
+        return rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
+                                 s.gaussian_values_sorted, w, h, settings.background, proj.packed);
+    };
+    SortingOutput srt;
+    ForwardOutput fwd;
+    const int num_tiles = ((w + CUGS_TILE - 1) / CUGS_TILE) * ((h + CUGS_TILE - 1) / CUGS_TILE);
+    auto known = last_pairs.find(dev_index);
+    if (known == last_pairs.end() || num_tiles == 0) {
+        srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
+        fwd = blend(srt);
+    } else {
+        const int64_t cap = std::min<int64_t>(known->second + known->second / 32 + 65536, 2147483647ll);
+        if (!pinned.count(dev_index)) pinned[dev_index] = torch::zeros({1}, torch::kInt64).pin_memory();
+        auto total = pinned[dev_index];
+        void* st = stream_of(proj.means_2d);
+        auto tiles = proj.tiles_touched.contiguous().to(torch::kInt32);
+        srt.tile_ranges = torch::empty({num_tiles, 2}, iopt(proj.means_2d));
+        srt.gaussian_values_sorted = torch::empty({cap}, iopt(proj.means_2d));
+        auto ws = workspace(proj.means_2d.device(), cugs_sort_workspace_bytes(n), 0);
+        auto wp = workspace(proj.means_2d.device(), cugs_sort_pair_workspace_bytes(cap), 1);
+        check(cugs_sort_pairs_predicted(n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii),
+                                        ptr<int32_t>(tiles), w, h, ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr,
+                                        ptr<int32_t>(srt.gaussian_values_sorted), ptr<int32_t>(srt.tile_ranges),
+                                        total.data_ptr<int64_t>(), st), "cugs_sort_pairs_predicted");
+        hipEvent_t ev;
+        TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+        TORCH_CHECK(hipEventRecord(ev, static_cast<hipStream_t>(st)) == hipSuccess, "hipEventRecord failed");
+        fwd = blend(srt);                                   // queued; the host has not waited yet
+        const bool ok = hipEventSynchronize(ev) == hipSuccess;
+        (void)hipEventDestroy(ev);
+        TORCH_CHECK(ok, "hipEventSynchronize failed");
+        const int64_t p = total.data_ptr<int64_t>()[0];
+        TORCH_CHECK(p >= 0 && p <= 2147483647ll, "pair count exceeds the reference's int indexing");
+        if (p <= cap) {
+            srt.total_pairs = static_cast<int>(p);
+            srt.gaussian_values_sorted = srt.gaussian_values_sorted.slice(0, 0, p);
+        } else {                                            // prediction too small: exact path, blend again
+            srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
+            fwd = blend(srt);
+        }
+    }
+    last_pairs[dev_index] = srt.total_pairs;
     if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] sorted P=%d\n", srt.total_pairs);
-    auto fwd = rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
-                                 srt.gaussian_values_sorted, w, h, settings.background, proj.packed);
     o.color = fwd.color; o.final_T = fwd.final_T; o.n_contrib = fwd.n_contrib;
     o.means_2d = proj.means_2d; o.depths = proj.depths; o.cov_2d_inv = proj.cov_2d_inv; o.radii = proj.radii;
     o.rgb = proj.rgb; o.opacities_act = proj.opacities_act;
