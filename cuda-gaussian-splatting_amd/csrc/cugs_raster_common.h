@@ -136,7 +136,7 @@ __device__ __forceinline__ float pixel_alpha(float pxf, float pyf, float mx, flo
     const float power = -0.5f * fmaf(r.dx, r.gx, r.dy * r.gy);
     float pw = fmaxf(power, -6.0f);
     pw = (power > 0.0f) ? -6.0f : pw;
-    r.e = cugs_expf_core(pw);
+    r.e = cugs_expf_small(pw);                                // pw in [-6, 0]: same bits as cugs_expf
     const float alpha = fminf((o * open) * r.e, 0.99f);       // o * 1.0f is exact
     return (alpha < (1.0f / 255.0f)) ? 0.0f : alpha;
 }

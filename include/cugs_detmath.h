@@ -50,7 +50,8 @@ CUGS_HD float cugs_pow2i(int k) { return cugs_bits_to_float((uint32_t)(k + 127) 
  * |r| <= ln2/2, degree-5 minimax polynomial for (e^r - 1 - r)/r^2 (the Cephes
  * expf coefficients), result scaled by 2^k in two exact steps.
  * Precondition (callers guarantee it): x finite and inside the range. */
-CUGS_HD float cugs_expf_core(float x) {
+/* The reduction and the polynomial: returns e^r in [0.70, 1.42] and k (as a float) with x = k ln2 + r. */
+CUGS_HD float cugs_expf_mant(float x, float* kf_out) {
     const float kLog2e = 1.44269504088896341f;
     const float kLn2Hi = 0.693359375f;          /* 8 significant bits: k*kLn2Hi is exact */
     const float kLn2Lo = -2.12194440e-4f;
@@ -64,11 +65,26 @@ CUGS_HD float cugs_expf_core(float x) {
     p = fmaf(p, r, 1.6666665459e-1f);
     p = fmaf(p, r, 5.0000001201e-1f);
     float r2 = r * r;
-    float e = fmaf(p, r2, r) + 1.0f;            /* in [0.70, 1.42] */
+    *kf_out = kf;
+    return fmaf(p, r2, r) + 1.0f;
+}
+
+CUGS_HD float cugs_expf_core(float x) {
+    float kf;
+    float e = cugs_expf_mant(x, &kf);
     int k = (int)kf;                            /* in [-126, 128] */
     int k1 = k >> 1;
     int k2 = k - k1;
     return (e * cugs_pow2i(k1)) * cugs_pow2i(k2);
+}
+
+/* The same function for |x| <= 80 (the blend evaluates it on [-6, 0] only): there the result is a normal
+ * number, so the two exact scalings are one addition of k to the exponent field - identical bits, five
+ * instructions fewer (tests/test_detmath.py compares the two on that range). */
+CUGS_HD float cugs_expf_small(float x) {
+    float kf;
+    float e = cugs_expf_mant(x, &kf);
+    return cugs_bits_to_float(cugs_float_to_bits(e) + ((uint32_t)(int)kf << 23));
 }
 
 /* exp(x), all inputs: NaN -> NaN, x > 88.72 -> +inf, x < -87.3 -> 0 (results

@@ -177,6 +177,13 @@ def expf(x: np.ndarray) -> np.ndarray:
     return y.reshape(np.shape(x))
 
 
+def expf_small(x: np.ndarray) -> np.ndarray:
+    xi = _f(x).reshape(-1)
+    y = np.empty_like(xi)
+    _lib.orc_expf_small_array(C.c_int64(xi.size), _p(xi), _p(y))
+    return y.reshape(np.shape(x))
+
+
 # ---- whole pipeline on numpy arrays (what tests compare the GPU against) ----------------
 def render(model: Dict[str, np.ndarray], rotation, translation, fx, fy, cx, cy, w, h, bg=(0.0, 0.0, 0.0),
            active_degree=3, scale_mod=1.0, rows=None) -> Dict[str, np.ndarray]:

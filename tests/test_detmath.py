@@ -38,3 +38,12 @@ def test_expf_preskip_bound(orc):
     assert float(orc.expf(np.array([x]))[0]) < 1.0 / 255.0
     xs = np.linspace(-87.0, -5.6, 200_001).astype(np.float32)
     assert orc.expf(xs).max() < 1.0 / 255.0
+
+
+def test_expf_small_is_bit_identical_on_its_range(orc):
+    """cugs_expf_small (one exponent-field addition instead of two exact scalings; what the blend kernels call
+    on [-6, 0]) returns the same bits as cugs_expf wherever the result is a normal number."""
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-6.0, 0.0, 1_000_000), rng.uniform(-80.0, 80.0, 300_000),
+                        np.linspace(-6.0, 0.0, 100_001), [0.0, -0.0, -6.0, -80.0, 80.0]]).astype(np.float32)
+    assert np.array_equal(orc.expf_small(x).view(np.uint32), orc.expf(x).view(np.uint32))
