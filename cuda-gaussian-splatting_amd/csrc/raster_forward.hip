@@ -36,7 +36,9 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
     const int num_in_range = range_end - range_start;
     const int num_batches = (num_in_range + CUGS_BLOCK - 1) / CUGS_BLOCK;
 
-    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    float T = 1.0f, C0 = 0.0f;
+    v2f C12 = {0.0f, 0.0f};                             // green/blue as one packed-fp32 accumulator (v_pk_fma_f32)
     int count = 0;
     float open = inside ? 1.0f : 0.0f;                  // 1 while the pixel still blends, 0 once T < 1/255
     bool wave_done = (__ballot(open != 0.0f) == 0ull);
@@ -70,8 +72,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
                     // al == 0 (skipped or finished pixel) leaves C, T and count untouched exactly
                     const float weight = al * T;
                     C0 = fmaf(weight, g1.y, C0);
-                    C1 = fmaf(weight, g1.z, C1);
-                    C2 = fmaf(weight, g1.w, C2);
+                    C12 = __builtin_elementwise_fma((v2f){weight, weight}, (v2f){g1.z, g1.w}, C12);   // record words 6,7: an aligned pair
                     T *= (1.0f - al);
                     count += (al != 0.0f) ? 1 : 0;
                     open = (T < (1.0f / 255.0f)) ? 0.0f : open;             // only a passing Gaussian can lower T
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
     if (inside) {
         const int pix = py * geo.width + px;
         out_color[pix * 3 + 0] = fmaf(T, geo.bg0, C0);
-        out_color[pix * 3 + 1] = fmaf(T, geo.bg1, C1);
-        out_color[pix * 3 + 2] = fmaf(T, geo.bg2, C2);
+        out_color[pix * 3 + 1] = fmaf(T, geo.bg1, C12.x);
+        out_color[pix * 3 + 2] = fmaf(T, geo.bg2, C12.y);
         out_final_T[pix] = T;
         out_n_contrib[pix] = count;
     }
