@@ -27,7 +27,33 @@ __device__ __forceinline__ void load_sh_rows(const float* __restrict__ sh, int64
     constexpr int ROW = ShTile<C>::ROW, LROW = ShTile<C>::LROW;
     const float* src = sh + base * ROW;
     const int total = count * ROW;
-    if (ALIGNED) {
+    const int tid = threadIdx.x;
+    if (ALIGNED && count == CUGS_BLOCK) {
+        // full workgroup: every thread issues ALL its 16-byte loads before the first LDS write, so the tile
+        // costs one HBM latency instead of one per loop iteration
+        constexpr int TOTAL4 = CUGS_BLOCK * ROW / 4, PER = (TOTAL4 + CUGS_BLOCK - 1) / CUGS_BLOCK;
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        float4 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e4 = tid + i * CUGS_BLOCK;
+            v[i] = (e4 < TOTAL4) ? src4[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e4 = tid + i * CUGS_BLOCK;
+            if (e4 < TOTAL4) {
+                int e = e4 * 4;
+                int row = e / ROW, col = e - row * ROW;
+                const float vals[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s_sh[row * LROW + col] = vals[k];
+                    if (++col == ROW) { col = 0; ++row; }
+                }
+            }
+        }
+    } else if (ALIGNED) {
         const int total4 = total >> 2;
         const float4* src4 = reinterpret_cast<const float4*>(src);
         for (int e4 = threadIdx.x; e4 < total4; e4 += CUGS_BLOCK) {

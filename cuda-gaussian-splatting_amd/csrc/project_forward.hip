@@ -28,7 +28,32 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ sh, int6
     const float* src = sh + base * ROW;
     const int total = count * ROW;
     const int tid = threadIdx.x;
-    if (ALIGNED) {
+    if (ALIGNED && count == CUGS_BLOCK) {
+        // full workgroup: every thread issues ALL its 16-byte loads before the first LDS write, so the tile
+        // costs one HBM latency instead of one per loop iteration
+        constexpr int TOTAL4 = CUGS_BLOCK * ROW / 4, PER = (TOTAL4 + CUGS_BLOCK - 1) / CUGS_BLOCK;
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        float4 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e4 = tid + i * CUGS_BLOCK;
+            v[i] = (e4 < TOTAL4) ? src4[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e4 = tid + i * CUGS_BLOCK;
+            if (e4 < TOTAL4) {
+                int e = e4 * 4;
+                int row = e / ROW, col = e - row * ROW;
+                const float vals[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s_sh[row * LROW + col] = vals[k];
+                    if (++col == ROW) { col = 0; ++row; }
+                }
+            }
+        }
+    } else if (ALIGNED) {
         const int total4 = total >> 2;
         const float4* src4 = reinterpret_cast<const float4*>(src);
         for (int e4 = tid; e4 < total4; e4 += CUGS_BLOCK) {
@@ -69,13 +94,20 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
 
     const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
     const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
+    // this thread's geometry inputs are requested before the SH tile, so that all of a workgroup's reads
+    // are in flight together (one HBM latency per workgroup, not one per phase)
+    const int64_t idx = base + threadIdx.x;
+    const bool live = idx < n;
+    const int64_t ld = live ? idx : (n - 1);
+    const V3 pos{p.positions[ld * 3 + 0], p.positions[ld * 3 + 1], p.positions[ld * 3 + 2]};
+    const float in_opa = p.opacities[ld];
+    const float in_s0 = p.scales[ld * 3 + 0], in_s1 = p.scales[ld * 3 + 1], in_s2 = p.scales[ld * 3 + 2];
+    const float4 q = ALIGNED ? reinterpret_cast<const float4*>(p.rotations)[ld]
+                             : make_float4(p.rotations[ld * 4 + 0], p.rotations[ld * 4 + 1],
+                                           p.rotations[ld * 4 + 2], p.rotations[ld * 4 + 3]);
     stage_sh_rows<C, ALIGNED>(p.sh, base, count, s_sh);
     __syncthreads();
-
-    const int64_t idx = base + threadIdx.x;
-    if (idx >= n) return;
-
-    const V3 pos{p.positions[idx * 3 + 0], p.positions[idx * 3 + 1], p.positions[idx * 3 + 2]};
+    if (!live) return;
 
     // --- colour: evaluated for every Gaussian, culled ones included ---
     const V3 dir = view_direction(pos, cam);
@@ -100,14 +132,9 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
         mx = cam.fx * t.x / t.z + cam.cx;
         my = cam.fy * t.y / t.z + cam.cy;
         depth = t.z;
-        opa = cugs_sigmoidf(p.opacities[idx]);
+        opa = cugs_sigmoidf(in_opa);
 
-        const V3 s{cugs_expf(p.scales[idx * 3 + 0] + cam.log_mod),
-                   cugs_expf(p.scales[idx * 3 + 1] + cam.log_mod),
-                   cugs_expf(p.scales[idx * 3 + 2] + cam.log_mod)};
-        const float4 q = ALIGNED ? reinterpret_cast<const float4*>(p.rotations)[idx]
-                                 : make_float4(p.rotations[idx * 4 + 0], p.rotations[idx * 4 + 1],
-                                               p.rotations[idx * 4 + 2], p.rotations[idx * 4 + 3]);
+        const V3 s{cugs_expf(in_s0 + cam.log_mod), cugs_expf(in_s1 + cam.log_mod), cugs_expf(in_s2 + cam.log_mod)};
         const QuatRot qr = rotation_of(q.x, q.y, q.z, q.w);
         const Sym3 S = gram(scale_columns(qr.R, s));
         const Jac J = jacobian(t, cam.fx, cam.fy);
