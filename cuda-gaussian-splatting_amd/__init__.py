@@ -19,4 +19,5 @@ from .fused_adam import (AdamConfig, FusedAdam, ParamGroup, PositionLRConfig,  #
                          active_sh_degree_for_step, lr_defaults, position_lr)
 from .loss import combined_loss, combined_loss_and_grad, l1_loss, ssim, ssim_loss  # noqa: F401
 from .densification import DensificationConfig, DensificationController, DensificationStats  # noqa: F401
+from .ply_io import read_gaussian_ply, restore_optimizer, write_gaussian_ply  # noqa: F401
 from . import parallel, scene  # noqa: F401

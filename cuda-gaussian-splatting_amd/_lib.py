@@ -73,6 +73,9 @@ SIGNATURES = {
     "cugs_densify_workspace_bytes": (C.c_size_t, [_L]),
     "cugs_densify_plan": (_I, [_L, _P, _P, C.c_size_t, C.POINTER(C.c_int64), _P]),
     "cugs_densify_apply": (_I, [_L, _L, _P, C.c_size_t, _P, _P, C.POINTER(DensifyArray), _I, _P]),
+    "cugs_ply_vertex_floats": (_I, [_I, _I]),
+    "cugs_ply_pack": (_I, [_L, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P]),
+    "cugs_ply_unpack": (_I, [_L, _I, _I, _P, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P]),
     "cugs_device_count": (_I, [C.POINTER(C.c_int)]),
 }
 

@@ -252,6 +252,25 @@ int cugs_densify_plan(int64_t n, const uint8_t* flags, void* workspace, size_t w
 int cugs_densify_apply(int64_t n, int64_t n_out, const void* workspace, size_t workspace_bytes, const float* noise,
                        const float* scales, const cugs_densify_array* arrays_host, int num_arrays, void* stream);
 
+/* ---- N3: Gaussian-model PLY records (utils/ply_io.cpp:98-196, 258-351) -------------------------
+ * The vertex record of the reference's checkpoint format, assembled / taken apart on the device:
+ *   x y z | nx ny nz (zero) | f_dc_0..2 | f_rest_0..3(C-1)-1 (f_rest_{(k-1)*3+ch} = sh[ch][k]) | opacity |
+ *   scale_0..2 | rot_0..3                                         = 14 + 3C floats (62 at SH degree 3),
+ * optionally followed by the Adam first and second moments in the same order without the normals (2 x (11 + 3C)
+ * floats): what a resumable checkpoint needs and the reference does not store.
+ * params / m / v: five device pointers each in ParamGroup order {positions, sh_coeffs, opacities, scales,
+ * rotations}; m and v both NULL = no optimizer state.
+ * cugs_ply_pack:   vertices [n, cugs_ply_vertex_floats(C, state)] <- the tensors.
+ * cugs_ply_unpack: the tensors <- vertices [n, num_props] as read from a file whose properties may be in any
+ *   order or include others: col_of[c] (device, 11 + 3C entries, x3 with state) is the file column of canonical
+ *   model float c (the record order above without the normals; then m, then v), looked up by NAME on the host.
+ */
+int cugs_ply_vertex_floats(int num_coeffs, int with_state);
+int cugs_ply_pack(int64_t n, int num_coeffs, const float* const params[5], const float* const m[5],
+                  const float* const v[5], float* vertices, void* stream);
+int cugs_ply_unpack(int64_t n, int num_coeffs, int num_props, const float* vertices, const int32_t* col_of,
+                    float* const params[5], float* const m[5], float* const v[5], void* stream);
+
 /* Device properties the host side needs without linking the HIP runtime itself. */
 int cugs_device_count(int* count_host);
 
