@@ -277,7 +277,7 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
         fwd = blend(srt);
     } else {
-        const int64_t cap = std::min<int64_t>(known->second + known->second / 32 + 65536, 2147483647ll);
+        const int64_t cap = std::min<int64_t>(known->second + known->second / 10 + 65536, 2147483647ll);
         if (!pinned.count(dev_index)) pinned[dev_index] = torch::zeros({1}, torch::kInt64).pin_memory();
         auto total = pinned[dev_index];
         void* st = stream_of(proj.means_2d);
@@ -307,7 +307,11 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
             fwd = blend(srt);
         }
     }
-    last_pairs[dev_index] = srt.total_pairs;
+    // running maximum with a slow decay: views differ by tens of percent, spare capacity is cheap, a miss is not
+    {
+        const int64_t prev = known == last_pairs.end() ? 0 : known->second;
+        last_pairs[dev_index] = std::max<int64_t>(srt.total_pairs, prev - prev / 200);
+    }
     if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] sorted P=%d\n", srt.total_pairs);
     o.color = fwd.color; o.final_T = fwd.final_T; o.n_contrib = fwd.n_contrib;
     o.means_2d = proj.means_2d; o.depths = proj.depths; o.cov_2d_inv = proj.cov_2d_inv; o.radii = proj.radii;

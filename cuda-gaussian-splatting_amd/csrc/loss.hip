@@ -9,7 +9,7 @@
 // Two launches over 16x16 pixel tiles (halo = window/2 in LDS):
 //   k_ssim_stats: x, y tiles -> separable window sums of x, y, x^2, y^2, xy -> SSIM per pixel/channel,
 //                 its partial derivatives w.r.t. (mu_x, E[x^2], E[xy]) as three maps, and the two loss sums
-//                 (fp64 atomics: the scalar does not depend on block order beyond fp64 rounding);
+//                 (one fp64 partial pair per tile, reduced in a fixed order: the scalar is deterministic);
 //   k_ssim_grad:  separable window sums of the three maps (the window is symmetric, so the adjoint of the
 //                 convolution is the convolution) -> dL/dx = (1-lambda) sign(x-y)/n - lambda/n (G_m + 2x G_p + y G_r).
 // With S = A1 A2 / (B1 B2), A1 = 2 m n + C1, A2 = 2 (r - m n) + C2, B1 = m^2 + n^2 + C1, B2 = (p - m^2) + (q - n^2) + C2
@@ -31,7 +31,9 @@ struct Window { float w[2 * MAX_R + 1]; int r; };
 // stride of 3 floats.
 // With a compile-time radius every thread first issues all its loads (NIMG images x <= 8 floats) and only then
 // writes LDS, so one HBM latency is paid per tile instead of one per element.
-template <int RT, int NIMG>
+// PAIR: images 0 and 1 are stored interleaved, element e at s_t[0][2e], s_t[0][2e+1] (one ds_read_b64 feeds a
+// packed-fp32 FMA with both); a third image, if any, goes to s_t[2] as usual.
+template <int RT, int NIMG, bool PAIR = false>
 __device__ __forceinline__ void load_tiles3(const float* const (&img)[NIMG], float* const (&s_t)[NIMG], int tx0, int ty0,
                                             int R, int E, int w, int h) {
     const int row_f = E * 3, total = E * row_f, w3 = w * 3;
@@ -52,8 +54,14 @@ __device__ __forceinline__ void load_tiles3(const float* const (&img)[NIMG], flo
         for (int i = 0; i < PER; ++i) {
             const int e = (int)threadIdx.x + i * CUGS_BLOCK;
             if (e < total) {
+                if constexpr (PAIR) {
+                    reinterpret_cast<float2*>(s_t[0])[e] = make_float2(v[0][i], v[1][i]);
 #pragma unroll
-                for (int m = 0; m < NIMG; ++m) s_t[m][e] = v[m][i];
+                    for (int m = 2; m < NIMG; ++m) s_t[m][e] = v[m][i];
+                } else {
+#pragma unroll
+                    for (int m = 0; m < NIMG; ++m) s_t[m][e] = v[m][i];
+                }
             }
         }
     } else {
@@ -89,10 +97,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_stats(int w, int h, Window 
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int px = tx0 + lx, py = ty0 + ly;
     const bool inside = px < w && py < h;
+    typedef float v2f __attribute__((ext_vector_type(2)));
     {
         const float* const imgs[2] = {xr, yt};
         float* const dst[2] = {s_x, s_y};
-        load_tiles3<RT, 2>(imgs, dst, tx0, ty0, R, E, w, h);
+        load_tiles3<RT, 2, ALIAS>(imgs, dst, tx0, ty0, R, E, w, h);     // compile-time radius: (x, y) interleaved
     }
     __syncthreads();
     // |x - y| at this thread's pixel, read before the tiles can be overwritten
@@ -100,7 +109,12 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_stats(int w, int h, Window 
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const int c = ((ly + R) * E + lx + R) * 3 + ch;
-        l1c[ch] = fabsf(s_x[c] - s_y[c]);
+        if constexpr (ALIAS) {
+            const float2 xy = reinterpret_cast<const float2*>(s_pool)[c];
+            l1c[ch] = fabsf(xy.x - xy.y);
+        } else {
+            l1c[ch] = fabsf(s_x[c] - s_y[c]);
+        }
     }
     // horizontal pass: E rows x 48 float columns (16 pixels x 3 channels), tap stride 3
     auto hsum = [&](int e, float (&o)[5]) {
@@ -117,21 +131,37 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_stats(int w, int h, Window 
         o[0] = a; o[1] = b; o[2] = aa; o[3] = bb; o[4] = ab;
     };
     if constexpr (ALIAS) {
+        // Packed fp32: (x, y) and (x^2, y^2) each advance with ONE v_pk_fma_f32 per tap - 5 VALU per tap instead
+        // of 8; the sums are stored as the pairs (mu_x, mu_y), (E[x^2], E[y^2]) and the single E[xy].
         constexpr int PER_H = (H_F + CUGS_BLOCK - 1) / CUGS_BLOCK;
-        float acc[PER_H][5];
+        const v2f* s_xy = reinterpret_cast<const v2f*>(s_pool);
+        v2f acc_ab[PER_H], acc_sq[PER_H];
+        float acc_xy[PER_H];
 #pragma unroll
         for (int i = 0; i < PER_H; ++i) {
             const int e = tid + i * CUGS_BLOCK;
-            if (e < H_F) hsum(e, acc[i]);
+            acc_ab[i] = (v2f){0.0f, 0.0f}; acc_sq[i] = (v2f){0.0f, 0.0f}; acc_xy[i] = 0.0f;
+            if (e < H_F) {
+                const int ey = e / CW, cf = e - ey * CW;
+                const v2f* row = s_xy + ey * E * 3 + cf;
+#pragma unroll
+                for (int k = 0; k <= 2 * R; ++k) {
+                    const float wk = win.w[k];
+                    const v2f xy = row[3 * k], wk2 = {wk, wk};
+                    acc_ab[i] = __builtin_elementwise_fma(wk2, xy, acc_ab[i]);
+                    acc_sq[i] = __builtin_elementwise_fma(wk2, xy * xy, acc_sq[i]);
+                    acc_xy[i] = fmaf(wk, xy.x * xy.y, acc_xy[i]);
+                }
+            }
         }
         __syncthreads();                                                 // every read of the input tiles is done
+        v2f* h_ab = reinterpret_cast<v2f*>(s_pool);
+        v2f* h_sq = reinterpret_cast<v2f*>(s_pool + 2 * H_F);
+        float* h_xy = s_pool + 4 * H_F;
 #pragma unroll
         for (int i = 0; i < PER_H; ++i) {
             const int e = tid + i * CUGS_BLOCK;
-            if (e < H_F) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k) s_hp[k * H_F + e] = acc[i][k];
-            }
+            if (e < H_F) { h_ab[e] = acc_ab[i]; h_sq[e] = acc_sq[i]; h_xy[e] = acc_xy[i]; }
         }
     } else {
         for (int e = tid; e < E * CW; e += CUGS_BLOCK) {
@@ -147,12 +177,29 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_stats(int w, int h, Window 
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         float m = 0.0f, n = 0.0f, p = 0.0f, q = 0.0f, r = 0.0f;
+        if constexpr (ALIAS) {
+            const v2f* h_ab = reinterpret_cast<const v2f*>(s_pool);
+            const v2f* h_sq = reinterpret_cast<const v2f*>(s_pool + 2 * H_F);
+            const float* h_xy = s_pool + 4 * H_F;
+            v2f mn = {0.0f, 0.0f}, pq = {0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k <= 2 * R; ++k) {
-            const float wk = win.w[k];
-            const int e = (ly + k) * CW + lx * 3 + ch;
-            m = fmaf(wk, s_hp[e], m); n = fmaf(wk, s_hp[H_F + e], n); p = fmaf(wk, s_hp[2 * H_F + e], p);
-            q = fmaf(wk, s_hp[3 * H_F + e], q); r = fmaf(wk, s_hp[4 * H_F + e], r);
+            for (int k = 0; k <= 2 * R; ++k) {
+                const float wk = win.w[k];
+                const v2f wk2 = {wk, wk};
+                const int e = (ly + k) * CW + lx * 3 + ch;
+                mn = __builtin_elementwise_fma(wk2, h_ab[e], mn);
+                pq = __builtin_elementwise_fma(wk2, h_sq[e], pq);
+                r = fmaf(wk, h_xy[e], r);
+            }
+            m = mn.x; n = mn.y; p = pq.x; q = pq.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k <= 2 * R; ++k) {
+                const float wk = win.w[k];
+                const int e = (ly + k) * CW + lx * 3 + ch;
+                m = fmaf(wk, s_hp[e], m); n = fmaf(wk, s_hp[H_F + e], n); p = fmaf(wk, s_hp[2 * H_F + e], p);
+                q = fmaf(wk, s_hp[3 * H_F + e], q); r = fmaf(wk, s_hp[4 * H_F + e], r);
+            }
         }
         if (inside) {
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
@@ -176,8 +223,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_stats(int w, int h, Window 
     if ((tid & 63) == 0) { s_red[0][tid >> 6] = l1_acc; s_red[1][tid >> 6] = ss_acc; }
     __syncthreads();
     if (tid == 0) {
-        atomicAdd(&sums[0], s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]);
-        atomicAdd(&sums[1], s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]);
+        // one partial pair per tile, summed (in fp64, in tile order: deterministic) by k_loss_finalize; thousands
+        // of fp64 atomics on one cache line serialise at the memory side
+        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        sums[2 * blk + 0] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        sums[2 * blk + 1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
     }
 }
 
@@ -205,10 +255,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_grad(int w, int h, Window w
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) { xv[ch] = xr[o + ch]; yv[ch] = yt[o + ch]; }
     }
+    typedef float v2f __attribute__((ext_vector_type(2)));
     {
         const float* const imgs[3] = {d_m, d_p, d_r};
         float* const dst[3] = {s_a[0], s_a[1], s_a[2]};
-        load_tiles3<RT, 3>(imgs, dst, tx0, ty0, R, E, w, h);
+        load_tiles3<RT, 3, ALIAS>(imgs, dst, tx0, ty0, R, E, w, h);     // compile-time radius: (d_m, d_p) interleaved
     }
     __syncthreads();
     auto hsum = [&](int e, float (&o)[3]) {
@@ -226,20 +277,31 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_grad(int w, int h, Window w
     };
     if constexpr (ALIAS) {
         constexpr int PER_H = (H_F + CUGS_BLOCK - 1) / CUGS_BLOCK;
-        float acc[PER_H][3];
+        const v2f* s_mp = reinterpret_cast<const v2f*>(s_pool);          // (d_m, d_p) pairs
+        v2f acc_mp[PER_H];
+        float acc_r[PER_H];
 #pragma unroll
         for (int i = 0; i < PER_H; ++i) {
             const int e = tid + i * CUGS_BLOCK;
-            if (e < H_F) hsum(e, acc[i]);
+            acc_mp[i] = (v2f){0.0f, 0.0f}; acc_r[i] = 0.0f;
+            if (e < H_F) {
+                const int ey = e / CW, cf = e - ey * CW;
+                const int base = ey * E * 3 + cf;
+#pragma unroll
+                for (int k = 0; k <= 2 * R; ++k) {
+                    const float wk = win.w[k];
+                    acc_mp[i] = __builtin_elementwise_fma((v2f){wk, wk}, s_mp[base + 3 * k], acc_mp[i]);
+                    acc_r[i] = fmaf(wk, s_a[2][base + 3 * k], acc_r[i]);
+                }
+            }
         }
         __syncthreads();
+        v2f* h_mp = reinterpret_cast<v2f*>(s_pool);
+        float* h_r = s_pool + 2 * H_F;
 #pragma unroll
         for (int i = 0; i < PER_H; ++i) {
             const int e = tid + i * CUGS_BLOCK;
-            if (e < H_F) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) s_hp[k * H_F + e] = acc[i][k];
-            }
+            if (e < H_F) { h_mp[e] = acc_mp[i]; h_r[e] = acc_r[i]; }
         }
     } else {
         for (int e = tid; e < E * CW; e += CUGS_BLOCK) {
@@ -254,11 +316,25 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_grad(int w, int h, Window w
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         float gm = 0.0f, gp = 0.0f, gr = 0.0f;
+        if constexpr (ALIAS) {
+            const v2f* h_mp = reinterpret_cast<const v2f*>(s_pool);
+            const float* h_r = s_pool + 2 * H_F;
+            v2f mp = {0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k <= 2 * R; ++k) {
-            const float wk = win.w[k];
-            const int e = (ly + k) * CW + lx * 3 + ch;
-            gm = fmaf(wk, s_hp[e], gm); gp = fmaf(wk, s_hp[H_F + e], gp); gr = fmaf(wk, s_hp[2 * H_F + e], gr);
+            for (int k = 0; k <= 2 * R; ++k) {
+                const float wk = win.w[k];
+                const int e = (ly + k) * CW + lx * 3 + ch;
+                mp = __builtin_elementwise_fma((v2f){wk, wk}, h_mp[e], mp);
+                gr = fmaf(wk, h_r[e], gr);
+            }
+            gm = mp.x; gp = mp.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k <= 2 * R; ++k) {
+                const float wk = win.w[k];
+                const int e = (ly + k) * CW + lx * 3 + ch;
+                gm = fmaf(wk, s_hp[e], gm); gp = fmaf(wk, s_hp[H_F + e], gp); gr = fmaf(wk, s_hp[2 * H_F + e], gr);
+            }
         }
         const int64_t o = ((int64_t)py * w + px) * 3 + ch;
         const float x = xv[ch], y = yv[ch], d = x - y;
@@ -268,8 +344,22 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_grad(int w, int h, Window w
 }
 
 // loss_out[0] = combined loss, [1] = L1 mean, [2] = mean SSIM, [3] = 1 - mean SSIM (ssim_loss)
-__global__ void k_loss_finalize(const double* __restrict__ sums, double count, float lambda, float* __restrict__ out) {
-    const double l1 = sums[0] / count, ss = sums[1] / count;
+__global__ __launch_bounds__(CUGS_BLOCK) void k_loss_finalize(const double* __restrict__ partials, int nblk, double count,
+                                                               float lambda, float* __restrict__ out) {
+    __shared__ double s_acc[2][CUGS_BLOCK];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += CUGS_BLOCK) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+    s_acc[0][threadIdx.x] = a; s_acc[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int d = CUGS_BLOCK / 2; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            s_acc[0][threadIdx.x] += s_acc[0][threadIdx.x + d];
+            s_acc[1][threadIdx.x] += s_acc[1][threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double l1 = s_acc[0][0] / count, ss = s_acc[1][0] / count;
     out[0] = (float)((1.0 - (double)lambda) * l1 + (double)lambda * (1.0 - ss));
     out[1] = (float)l1;
     out[2] = (float)ss;
@@ -280,7 +370,8 @@ __global__ void k_loss_finalize(const double* __restrict__ sums, double count, f
 
 extern "C" size_t cugs_loss_workspace_bytes(int width, int height) {
     if (width < 0 || height < 0) return 0;
-    return 256 + sizeof(float) * 3 * 3 * (size_t)width * (size_t)height;
+    const size_t tiles = (size_t)((width + LT - 1) / LT) * (size_t)((height + LT - 1) / LT);
+    return 256 + (16 * tiles + 255) / 256 * 256 + sizeof(float) * 3 * 3 * (size_t)width * (size_t)height;
 }
 
 extern "C" int cugs_combined_loss(int width, int height, const float* rendered, const float* target, float lambda,
@@ -309,19 +400,20 @@ extern "C" int cugs_combined_loss(int width, int height, const float* rendered, 
         for (int j = 0; j < window_size; ++j) s2 += (double)(k1[i] * k1[j]);
     for (int i = 0; i < 2 * MAX_R + 1; ++i) win.w[i] = i < window_size ? (float)((double)k1[i] / sqrt(s2)) : 0.0f;
 
-    double* sums = static_cast<double*>(workspace);
+    dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT), block(CUGS_BLOCK);
+    const size_t tiles = (size_t)grid.x * grid.y;
+    double* sums = reinterpret_cast<double*>(static_cast<char*>(workspace) + 256);     // [tiles][2] partial sums
     const size_t plane = 3 * (size_t)width * (size_t)height;
-    float* d_m = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    float* d_m = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256 + (16 * tiles + 255) / 256 * 256);
     float* d_p = d_m + plane;
     float* d_r = d_p + plane;
-    CUGS_RETURN_IF_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(double), st));
-    dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT), block(CUGS_BLOCK);
     if (win.r == 5)      // the reference's default window (11): compile-time radius
         hipLaunchKernelGGL(k_ssim_stats<5>, grid, block, 0, st, width, height, win, rendered, target, d_m, d_p, d_r, ssim_map, sums);
     else
         hipLaunchKernelGGL(k_ssim_stats<0>, grid, block, 0, st, width, height, win, rendered, target, d_m, d_p, d_r, ssim_map, sums);
     CUGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, sums, (double)width * height * 3.0, lambda, loss_out);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(CUGS_BLOCK), 0, st, sums, (int)tiles, (double)width * height * 3.0, lambda,
+                       loss_out);
     CUGS_LAUNCH_CHECK();
     if (dL_dcolor) {
         if (win.r == 5)

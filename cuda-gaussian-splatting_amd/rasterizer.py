@@ -186,8 +186,11 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
 # device predicts this frame's; the host keeps launching (the forward blend) while the sort runs and reads
 # the true count afterwards.  A wrong prediction is detected then and the exact path is taken instead.
 # --------------------------------------------------------------------------------------
-_last_pairs = {}                    # device -> pair count of the last sort
-PREDICT_MARGIN = (1.03, 65536)      # capacity = last * 1.03 + 64 Ki
+# device -> running estimate of the pair count: max(count of the last sort, 0.995 x previous estimate).  Training
+# walks over views whose counts differ by tens of percent; an estimate that tracks the recent MAXIMUM keeps the
+# capacity sufficient (spare capacity costs a few empty workgroups, a miss costs a wasted sort and blend).
+_last_pairs = {}
+PREDICT_MARGIN = (1.10, 65536)      # capacity = estimate * 1.10 + 64 Ki
 
 
 class PendingSort:
@@ -206,7 +209,8 @@ class PendingSort:
         p = int(self._total[0])
         means_2d, depths, radii, tiles, img_w, img_h, want_keys = self._args
         _torch_check(0 <= p <= 2147483647, "pair count exceeds the reference's int indexing")
-        _last_pairs[means_2d.device] = p
+        prev = _last_pairs.get(means_2d.device, 0)
+        _last_pairs[means_2d.device] = p if p > self.capacity else max(p, int(prev * 0.995))
         if p <= self.capacity:
             keys = self._keys[:p] if want_keys else self._keys
             return SortingOutput(keys, self._vals[:p], self.tile_ranges, p), True

@@ -101,7 +101,7 @@ def test_sort_predicted_capacity_path(pkg, orc, dev):
             assert np.array_equal(np_(srt.gaussian_keys_sorted).view(np.uint64), ref["keys"])
             assert np.array_equal(np_(srt.gaussian_values_sorted), ref["values"])
             assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])
-            assert R._last_pairs[torch.device(dev)] == ref["total_pairs"]
+            assert R._last_pairs[torch.device(dev)] >= ref["total_pairs"]          # running maximum, slow decay
         # nothing visible: the predicted path must leave every tile {0,0} and report zero pairs
         R._last_pairs[torch.device(dev)] = 1000
         z = torch.zeros(50, dtype=torch.int32, device=dev)
