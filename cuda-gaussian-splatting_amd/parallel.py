@@ -59,7 +59,7 @@ def collect_views(grads: BackwardOutput, gated_rgb: torch.Tensor, cam_center: to
     reading the geometry gradients), so the caller can rebuild the SH gradient underneath it."""
     n = gated_rgb.shape[0]
     if not dist.is_initialized():
-        return gated_rgb.reshape(1, n, 3), cam_center.reshape(1, 3), []
+        return gated_rgb.reshape(1, n, 3), (cam_center.reshape(1, 3) if cam_center is not None else None), []
     world = dist.get_world_size(group)          # a 1-rank group still goes through the collectives
     # outputs are the rank-order concatenation along dim 0 (the shape both RCCL and gloo accept)
     views = torch.empty((world * n, 3), dtype=gated_rgb.dtype, device=gated_rgb.device)
@@ -90,7 +90,10 @@ def exchange_gradients(grads: BackwardOutput, gated_rgb: torch.Tensor, positions
     values, if every rank knows every view's camera) saves the gather of the centres and its device-to-host
     read.  The SH rebuild runs while the geometry all-reduce is still on the wire."""
     from .rasterizer import sh_backward_views
-    cc = torch.as_tensor(cam_center, dtype=torch.float32, device=gated_rgb.device).reshape(3)
+    # the device copy of this rank's centre is only needed when the centres have to be gathered (a pageable
+    # host-to-device copy would stall the launching thread behind the backward kernels)
+    cc = torch.as_tensor(cam_center, dtype=torch.float32, device=gated_rgb.device).reshape(3) \
+        if all_cam_centers is None else None
     views, centres, pending = collect_views(grads, gated_rgb, cc, group, need_centres=all_cam_centers is None,
                                             defer_geometry=True)
     host_centres = all_cam_centers if all_cam_centers is not None else centres.cpu().tolist()
