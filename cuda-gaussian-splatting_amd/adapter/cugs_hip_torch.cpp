@@ -310,7 +310,7 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     // running maximum with a slow decay: views differ by tens of percent, spare capacity is cheap, a miss is not
     {
         const int64_t prev = known == last_pairs.end() ? 0 : known->second;
-        last_pairs[dev_index] = std::max<int64_t>(srt.total_pairs, prev - prev / 200);
+        last_pairs[dev_index] = std::max<int64_t>(srt.total_pairs, prev - prev / 32);
     }
     if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] sorted P=%d\n", srt.total_pairs);
     o.color = fwd.color; o.final_T = fwd.final_T; o.n_contrib = fwd.n_contrib;

@@ -186,7 +186,7 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
 # device predicts this frame's; the host keeps launching (the forward blend) while the sort runs and reads
 # the true count afterwards.  A wrong prediction is detected then and the exact path is taken instead.
 # --------------------------------------------------------------------------------------
-# device -> running estimate of the pair count: max(count of the last sort, 0.995 x previous estimate).  Training
+# device -> running estimate of the pair count: max(count of the last sort, 0.97 x previous estimate).  Training
 # walks over views whose counts differ by tens of percent; an estimate that tracks the recent MAXIMUM keeps the
 # capacity sufficient (spare capacity costs a few empty workgroups, a miss costs a wasted sort and blend).
 _last_pairs = {}
@@ -210,7 +210,7 @@ class PendingSort:
         means_2d, depths, radii, tiles, img_w, img_h, want_keys = self._args
         _torch_check(0 <= p <= 2147483647, "pair count exceeds the reference's int indexing")
         prev = _last_pairs.get(means_2d.device, 0)
-        _last_pairs[means_2d.device] = p if p > self.capacity else max(p, int(prev * 0.995))
+        _last_pairs[means_2d.device] = p if p > self.capacity else max(p, int(prev * 0.97))
         if p <= self.capacity:
             keys = self._keys[:p] if want_keys else self._keys
             return SortingOutput(keys, self._vals[:p], self.tile_ranges, p), True
