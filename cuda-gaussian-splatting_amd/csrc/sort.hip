@@ -206,14 +206,21 @@ __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, u
 __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(uint32_t* __restrict__ hist,
                                                                 uint32_t nblk, uint32_t* __restrict__ tot) {
     __shared__ uint32_t s_tmp[4];
+    constexpr int PER = 8;                                   // consecutive entries per thread: 2048 per iteration
     uint32_t* row = hist + (size_t)blockIdx.x * nblk;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < nblk; base += CUGS_BLOCK) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < nblk ? row[i] : 0u;
+    for (uint32_t base = 0; base < nblk; base += CUGS_BLOCK * PER) {
+        const uint32_t i0 = base + threadIdx.x * PER;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) { v[e] = (i0 + e < nblk) ? row[i0 + e] : 0u; sum += v[e]; }
         uint32_t total;
-        uint32_t ex = block_exclusive_scan(v, s_tmp, &total);
-        if (i < nblk) row[i] = carry + ex;
+        uint32_t run = carry + block_exclusive_scan(sum, s_tmp, &total);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            if (i0 + e < nblk) row[i0 + e] = run;
+            run += v[e];
+        }
         carry += total;
     }
     if (threadIdx.x == 0) tot[blockIdx.x] = carry;
@@ -474,23 +481,43 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t pairs_or_ca
                                                             int32_t* __restrict__ tile_ranges,
                                                             uint64_t* __restrict__ keys_sorted,
                                                             const uint32_t* __restrict__ zero_pairs) {
+    constexpr int PER = 8;                                   // consecutive pairs per thread (one or two 16-byte loads)
     const uint32_t total_pairs = live_count(pairs_or_cap, dev_count);
-    const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
-    if (i >= total_pairs) return;
-    const uint32_t cur = ptile[i];
-    if (i == 0) {
-        tile_ranges[cur * 2 + 0] = 0;
+    const uint32_t i0 = (blockIdx.x * CUGS_BLOCK + threadIdx.x) * PER;
+    if (i0 >= total_pairs) return;
+    uint32_t t[PER];
+    if (i0 + PER <= total_pairs) {
+        if (sizeof(K) == 2) {
+            const uint4 q = *reinterpret_cast<const uint4*>(ptile + i0);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { t[2 * e] = w[e] & 0xFFFFu; t[2 * e + 1] = w[e] >> 16; }
+        } else {
+            const uint4 q0 = reinterpret_cast<const uint4*>(ptile + i0)[0], q1 = reinterpret_cast<const uint4*>(ptile + i0)[1];
+            t[0] = q0.x; t[1] = q0.y; t[2] = q0.z; t[3] = q0.w; t[4] = q1.x; t[5] = q1.y; t[6] = q1.z; t[7] = q1.w;
+        }
     } else {
-        const uint32_t prev = ptile[i - 1];
-        if (cur != prev) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) t[e] = (i0 + e < total_pairs) ? (uint32_t)ptile[i0 + e] : 0u;
+    }
+    uint32_t prev = (i0 == 0) ? 0u : (uint32_t)ptile[i0 - 1];
+    const uint32_t nzero = keys_sorted ? *zero_pairs : 0u;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const uint32_t i = i0 + e;
+        if (i >= total_pairs) break;
+        const uint32_t cur = t[e];
+        if (i == 0) {
+            tile_ranges[cur * 2 + 0] = 0;
+        } else if (cur != prev) {
             tile_ranges[prev * 2 + 1] = (int32_t)i;
             tile_ranges[cur * 2 + 0] = (int32_t)i;
         }
+        if (i == total_pairs - 1) tile_ranges[cur * 2 + 1] = (int32_t)total_pairs;
+        if (keys_sorted)   // Q12 pairs are the leading entries of tile 0 and carry depth bits 0
+            keys_sorted[i] = (i < nzero) ? 0ull : (((uint64_t)cur << 32) | (uint64_t)__float_as_uint(depths[pidx[i]]));
+        prev = cur;
     }
-    if (i == total_pairs - 1) tile_ranges[cur * 2 + 1] = (int32_t)total_pairs;
-    if (keys_sorted)   // Q12 pairs are the leading entries of tile 0 and carry depth bits 0
-        keys_sorted[i] = (i < *zero_pairs) ? 0ull
-                                            : (((uint64_t)cur << 32) | (uint64_t)__float_as_uint(depths[pidx[i]]));
 }
 
 template <typename K, bool IOTA, int NT>
@@ -557,7 +584,7 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         if (rc) return rc;
         cur ^= 1;
     }
-    hipLaunchKernelGGL((k_tile_ranges<K>), dim3(nblocks_for(up, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, up, dev_count, tk[cur],
+    hipLaunchKernelGGL((k_tile_ranges<K>), dim3(nblocks_for(up, CUGS_BLOCK * 8)), dim3(CUGS_BLOCK), 0, st, up, dev_count, tk[cur],
                        values_sorted, depths, tile_ranges, keys_sorted, ctl + 1);
     CUGS_LAUNCH_CHECK();
     return 0;
