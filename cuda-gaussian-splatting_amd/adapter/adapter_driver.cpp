@@ -81,6 +81,20 @@ int main(int argc, char** argv) {
             opt.apply_gradients(cugs_hip::render_backward(g, cugs_hip::render(m, cam, st), m, cam, st));
             opt.step();                                  // the optimizer still works on the resized model
         }
+        // N3 through the C++ host: checkpoint with optimizer state, read it back, compare
+        {
+            const std::string ply = d + "/out_model.ply";
+            bool ok = cugs_hip::write_gaussian_ply(ply, m, &opt);
+            cugs_hip::FusedAdam opt2({m.positions, m.sh_coeffs, m.opacities, m.scales, m.rotations},
+                                     {1.6e-4f, 2.5e-3f, 0.05f, 5e-3f, 1e-3f});
+            auto back = cugs_hip::read_gaussian_ply(ply, m.positions.device(), &opt2);
+            ok = ok && torch::equal(back.positions, m.positions) && torch::equal(back.sh_coeffs, m.sh_coeffs) &&
+                 torch::equal(back.opacities, m.opacities) && torch::equal(back.scales, m.scales) &&
+                 torch::equal(back.rotations, m.rotations);
+            bool threw_missing = false;
+            try { cugs_hip::read_gaussian_ply(d + "/no_such.ply"); } catch (const std::runtime_error&) { threw_missing = true; }
+            printf("ply roundtrip=%d missing_throws=%d\n", ok ? 1 : 0, threw_missing ? 1 : 0);
+        }
         // the reference's TORCH_CHECK behaviour: a CPU tensor must be rejected with c10::Error
         bool threw = false;
         try { cugs_hip::evaluate_sh_cuda(1, torch::zeros({2, 3, 4}), torch::zeros({2, 3})); } catch (const c10::Error&) { threw = true; }

@@ -3,6 +3,7 @@
 // torch's current HIP stream, turn a non-zero return into std::runtime_error.
 #include "cugs_hip_torch.hpp"
 
+#include <c10/hip/HIPFunctions.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
@@ -536,6 +537,139 @@ DensificationStats DensificationController::densify(ModelTensors& model, int ste
     stats.num_after = static_cast<int>(n_out);
     reset_accumulators(n_out, dev);                                               // :321
     return stats;
+}
+
+// ---------------------------------------------------------------------------------------------
+// N3: PLY checkpoints (utils/ply_io.cpp:98-196, 258-351)
+// ---------------------------------------------------------------------------------------------
+namespace {
+std::vector<std::string> ply_model_names(int c) {                 // record order without the normals
+    std::vector<std::string> n = {"x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"};
+    for (int i = 0; i < 3 * (c - 1); ++i) n.push_back("f_rest_" + std::to_string(i));
+    for (const char* p : {"opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"}) n.push_back(p);
+    return n;
+}
+}  // namespace
+
+bool write_gaussian_ply(const std::string& path, const ModelTensors& model, const FusedAdam* optimizer) {
+    const auto& p0 = model.positions;
+    if (!p0.defined() || p0.dim() != 2 || p0.size(1) != 3 || !model.sh_coeffs.defined() || model.sh_coeffs.dim() != 3 ||
+        model.sh_coeffs.size(0) != p0.size(0) || model.sh_coeffs.size(1) != 3 || model.opacities.numel() != p0.size(0) ||
+        model.scales.numel() != 3 * p0.size(0) || model.rotations.numel() != 4 * p0.size(0))
+        return false;                                             // ply_io.cpp:100-103 (is_valid)
+    const auto dev = p0.is_cuda() ? p0.device() : torch::Device(torch::kCUDA, c10::hip::current_device());
+    auto f32 = [&](const torch::Tensor& t) { return t.to(dev).contiguous().to(torch::kFloat32); };
+    std::array<torch::Tensor, 5> pr = {f32(model.positions), f32(model.sh_coeffs), f32(model.opacities), f32(model.scales),
+                                       f32(model.rotations)}, mm, vv;
+    const int64_t n = pr[0].size(0);
+    const int c = static_cast<int>(pr[1].size(2));
+    const bool state = optimizer != nullptr;
+    const float *pp[5], *pm[5], *pv[5];
+    for (int i = 0; i < 5; ++i) {
+        pp[i] = pr[i].data_ptr<float>();
+        if (state) { mm[i] = f32(optimizer->m_[i]); vv[i] = f32(optimizer->v_[i]); pm[i] = mm[i].data_ptr<float>(); pv[i] = vv[i].data_ptr<float>(); }
+    }
+    const int row = cugs_ply_vertex_floats(c, state ? 1 : 0);
+    auto verts = torch::empty({n, row}, fopt(pr[0]));
+    check(cugs_ply_pack(n, c, pp, state ? pm : nullptr, state ? pv : nullptr, ptr<float>(verts), stream_of(pr[0])), "cugs_ply_pack");
+    auto host = verts.cpu();                                      // one device-to-host copy of the finished records
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::string head = "ply\nformat binary_little_endian 1.0\n";
+    if (state) head += "comment cugs_adam_step " + std::to_string(optimizer->step_count_) + "\n";
+    head += "element vertex " + std::to_string(n) + "\n";
+    auto names = ply_model_names(c);
+    auto emit = [&](const std::string& prefix, bool normals) {
+        for (size_t i = 0; i < names.size(); ++i) {
+            head += "property float " + prefix + names[i] + "\n";
+            if (normals && i == 2) head += "property float nx\nproperty float ny\nproperty float nz\n";
+        }
+    };
+    emit("", true);
+    if (state) { emit("m_", false); emit("v_", false); }
+    head += "end_header\n";
+    bool ok = fwrite(head.data(), 1, head.size(), f) == head.size();
+    const size_t bytes = static_cast<size_t>(n) * row * sizeof(float);
+    ok = ok && (bytes == 0 || fwrite(host.data_ptr<float>(), 1, bytes, f) == bytes);
+    return (fclose(f) == 0) && ok;
+}
+
+ModelTensors read_gaussian_ply(const std::string& path, const torch::Device& device, FusedAdam* optimizer) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Failed to open PLY file: " + path);
+    std::string buf;
+    {
+        char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof(chunk), f)) > 0) buf.append(chunk, got);
+        fclose(f);
+    }
+    // parse_ply_header (ply_io.cpp:211-250)
+    size_t pos = 0;
+    std::vector<std::string> lines;
+    while (true) {
+        const size_t end = buf.find('\n', pos);
+        if (end == std::string::npos) throw std::runtime_error("Not a PLY file");
+        std::string line = buf.substr(pos, end - pos);
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        pos = end + 1;
+        lines.push_back(line);
+        if (line == "end_header") break;
+    }
+    if (lines[0].find("ply") == std::string::npos) throw std::runtime_error("Not a PLY file");
+    if (lines.size() < 2 || lines[1].find("binary_little_endian") == std::string::npos)
+        throw std::runtime_error("Only binary_little_endian PLY is supported");
+    int64_t n = 0;
+    long step = 0;
+    std::vector<std::string> names;
+    for (size_t i = 2; i < lines.size(); ++i) {
+        char a[64] = {0}, b[64] = {0}, c3[64] = {0};
+        const int got = sscanf(lines[i].c_str(), "%63s %63s %63s", a, b, c3);
+        if (got >= 3 && std::string(a) == "element" && std::string(b) == "vertex") n = atoll(c3);
+        else if (got >= 3 && std::string(a) == "property") names.push_back(c3);
+        else if (got == 3 && std::string(a) == "comment" && std::string(b) == "cugs_adam_step") step = atol(c3);
+    }
+    std::map<std::string, int> index;
+    for (size_t i = 0; i < names.size(); ++i) index[names[i]] = static_cast<int>(i);
+    int num_rest = 0;
+    while (index.count("f_rest_" + std::to_string(num_rest))) ++num_rest;
+    const int c = 1 + num_rest / 3;                               // :283
+    const bool state = optimizer != nullptr && index.count("m_x") && index.count("v_x");
+    auto canon = ply_model_names(c);
+    std::vector<int32_t> col_of;
+    for (const char* prefix : {"", "m_", "v_"}) {
+        if (prefix[0] && !state) break;
+        for (auto& nm : canon) {
+            auto it = index.find(std::string(prefix) + nm);
+            if (it == index.end()) throw std::runtime_error("Missing PLY property: " + std::string(prefix) + nm);
+            col_of.push_back(it->second);
+        }
+    }
+    const int num_props = static_cast<int>(names.size());
+    if (buf.size() - pos < static_cast<size_t>(n) * num_props * sizeof(float)) throw std::runtime_error("Failed to read PLY binary data");
+    const auto work = device.is_cuda() ? device : torch::Device(torch::kCUDA, c10::hip::current_device());
+    auto data = torch::from_blob(const_cast<char*>(buf.data() + pos), {n * num_props}, torch::kFloat32).to(work);
+    auto cols = torch::from_blob(col_of.data(), {static_cast<int64_t>(col_of.size())}, torch::kInt32).to(work);
+    auto o = torch::TensorOptions().dtype(torch::kFloat32).device(work);
+    auto mk = [&] { return std::array<torch::Tensor, 5>{torch::empty({n, 3}, o), torch::empty({n, 3, c}, o), torch::empty({n, 1}, o),
+                                                        torch::empty({n, 3}, o), torch::empty({n, 4}, o)}; };
+    auto pr = mk();
+    std::array<torch::Tensor, 5> mm, vv;
+    float *pp[5], *pm[5], *pv[5];
+    if (state) { mm = mk(); vv = mk(); }
+    for (int i = 0; i < 5; ++i) { pp[i] = ptr<float>(pr[i]); if (state) { pm[i] = ptr<float>(mm[i]); pv[i] = ptr<float>(vv[i]); } }
+    check(cugs_ply_unpack(n, c, num_props, ptr<float>(data), cols.data_ptr<int32_t>(), pp, state ? pm : nullptr,
+                          state ? pv : nullptr, stream_of(data)), "cugs_ply_unpack");
+    ModelTensors m{pr[0].to(device), pr[1].to(device), pr[2].to(device), pr[4].to(device), pr[3].to(device)};
+    if (state) {
+        for (int i = 0; i < 5; ++i) {
+            TORCH_CHECK(optimizer->m_[i].sizes() == mm[i].sizes(), "optimizer state shape mismatch");
+            optimizer->m_[i] = mm[i].to(optimizer->m_[i].device());
+            optimizer->v_[i] = vv[i].to(optimizer->v_[i].device());
+        }
+        optimizer->step_count_ = static_cast<int>(step);
+    }
+    return m;
 }
 
 }  // namespace cugs_hip

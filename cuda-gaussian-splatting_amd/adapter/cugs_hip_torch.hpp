@@ -11,6 +11,7 @@
 #include <torch/torch.h>
 
 #include <array>
+#include <string>
 
 #include "../../include/cugs_hip.h"
 
@@ -95,6 +96,8 @@ public:
     void step();
 private:
     friend class DensificationController;      // carries m_/v_ through clone/split/prune
+    friend bool write_gaussian_ply(const std::string&, const ModelTensors&, const FusedAdam*);
+    friend ModelTensors read_gaussian_ply(const std::string&, const torch::Device&, FusedAdam*);
     std::array<torch::Tensor, 5> params_, m_, v_, grads_;
     std::array<float, 5> lrs_;
     AdamHyper h_;
@@ -128,5 +131,13 @@ private:
     float scene_extent_;
     torch::Tensor grad_accum_, grad_count_, max_radii_2d_;
 };
+
+// utils/ply_io.hpp:53-64 over csrc/ply.hip: the reference's binary PLY layout, records packed and
+// unpacked on the device.  `optimizer` (optional): the Adam moments and step count ride along as extra properties
+// m_*, v_* and a header comment (the reference's reader skips both); read_gaussian_ply restores them into
+// `optimizer` when the file has them.  Errors as in the reference: write returns false, read throws.
+bool write_gaussian_ply(const std::string& path, const ModelTensors& model, const FusedAdam* optimizer = nullptr);
+ModelTensors read_gaussian_ply(const std::string& path, const torch::Device& device = torch::kCPU,
+                               FusedAdam* optimizer = nullptr);
 
 }  // namespace cugs_hip

@@ -66,6 +66,15 @@ def test_cpp_adapter_matches_python_host(pkg, dev, tmp_path):
                                                                grad_threshold=2e-7), 6.0)
     ctrl.accumulate_gradients(grads.dL_dmeans_2d, out.radii)
     stats = ctrl.densify(model, 5, noise.to(dev), optimizer=opt)
+    # N3 through the C++ host: its checkpoint (with optimizer state) round-trips there, loads here, and the
+    # Python writer reproduces the file byte for byte from what it loaded
+    assert "ply roundtrip=1 missing_throws=1" in res.stdout
+    ck_model, ck_state = pkg.read_gaussian_ply(tmp_path / "out_model.ply", device=dev, return_state=True)
+    assert ck_state is not None and ck_state["step"] == 2 and ck_model.is_valid()
+    ck_opt = pkg.FusedAdam(ck_model)
+    pkg.restore_optimizer(ck_opt, ck_state)
+    assert pkg.write_gaussian_ply(tmp_path / "rewritten.ply", ck_model, optimizer=ck_opt)
+    assert (tmp_path / "rewritten.ply").read_bytes() == (tmp_path / "out_model.ply").read_bytes()
     line = [l for l in res.stdout.splitlines() if l.startswith("densify ")][0]
     got = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in line.split()[1:]}
     assert stats.num_cloned > 0 and stats.num_split > 0 and stats.num_pruned > stats.num_split
