@@ -76,6 +76,7 @@ SIGNATURES = {
     "cugs_ply_vertex_floats": (_I, [_I, _I]),
     "cugs_ply_pack": (_I, [_L, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "cugs_ply_unpack": (_I, [_L, _I, _I, _P, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P]),
+    "cugs_image_to_float": (_I, [_I, _I, _P, _I, _I, _P, _P]),
     "cugs_device_count": (_I, [C.POINTER(C.c_int)]),
 }
 

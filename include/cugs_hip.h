@@ -271,6 +271,14 @@ int cugs_ply_pack(int64_t n, int num_coeffs, const float* const params[5], const
 int cugs_ply_unpack(int64_t n, int num_coeffs, int num_props, const float* vertices, const int32_t* col_of,
                     float* const params[5], float* const m[5], float* const v[5], void* stream);
 
+/* ---- N4: training target from a cached 8-bit view (data/image_io.cpp:35-39, 47-100) -------------
+ * dst [dst_height, dst_width, 3] float <- src [src_height, src_width, 3] uint8 (device, decoded once by the
+ * caller): value * (1/255), and - when the sizes differ - the reference's resize_image (pixel-centre bilinear,
+ * clamped edges, same fp32 operation order), i.e. the tensor trainer.cpp:186-198 builds on the CPU and uploads
+ * every iteration, bit for bit. */
+int cugs_image_to_float(int src_width, int src_height, const uint8_t* src_rgb8, int dst_width, int dst_height,
+                        float* dst, void* stream);
+
 /* Device properties the host side needs without linking the HIP runtime itself. */
 int cugs_device_count(int* count_host);
 
