@@ -81,6 +81,12 @@ int main(int argc, char** argv) {
             opt.apply_gradients(cugs_hip::render_backward(g, cugs_hip::render(m, cam, st), m, cam, st));
             opt.step();                                  // the optimizer still works on the resized model
         }
+        // N4 through the C++ host: the 8-bit copy of the render, half-size float target
+        {
+            auto u8 = (out.color.clamp(0, 1) * 255.0f).to(torch::kUInt8).contiguous();
+            save(d + "/out_view_u8.bin", u8);
+            save(d + "/out_target_half.bin", cugs_hip::image_to_float(u8, w / 2, h / 2));
+        }
         // N3 through the C++ host: checkpoint with optimizer state, read it back, compare
         {
             const std::string ply = d + "/out_model.ply";

@@ -539,6 +539,18 @@ DensificationStats DensificationController::densify(ModelTensors& model, int ste
     return stats;
 }
 
+// N4: training target from a cached 8-bit view
+torch::Tensor image_to_float(const torch::Tensor& view_u8, int width, int height) {
+    TORCH_CHECK(view_u8.is_cuda() && view_u8.dtype() == torch::kUInt8 && view_u8.dim() == 3 && view_u8.size(2) == 3,
+                "image must be a uint8 [H, W, 3] CUDA tensor");
+    if (width <= 0 || height <= 0) throw std::runtime_error("Invalid target dimensions for resize");   // image_io.cpp:48-50
+    auto src = view_u8.contiguous();
+    auto dst = torch::empty({height, width, 3}, torch::TensorOptions().dtype(torch::kFloat32).device(src.device()));
+    check(cugs_image_to_float(static_cast<int>(src.size(1)), static_cast<int>(src.size(0)), src.data_ptr<uint8_t>(), width,
+                              height, dst.data_ptr<float>(), stream_of(src)), "cugs_image_to_float");
+    return dst;
+}
+
 // ---------------------------------------------------------------------------------------------
 // N3: PLY checkpoints (utils/ply_io.cpp:98-196, 258-351)
 // ---------------------------------------------------------------------------------------------

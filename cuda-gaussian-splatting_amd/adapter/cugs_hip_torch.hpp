@@ -132,6 +132,11 @@ private:
     torch::Tensor grad_accum_, grad_count_, max_radii_2d_;
 };
 
+// the float [height, width, 3] training target from a device-resident uint8 [h, w, 3] view - x 1/255
+// and, if the sizes differ, the reference's resize_image (data/image_io.cpp:35-39, 47-100), bit for bit what
+// trainer.cpp:186-198 builds on the CPU and uploads.
+torch::Tensor image_to_float(const torch::Tensor& view_u8, int width, int height);
+
 // utils/ply_io.hpp:53-64 over csrc/ply.hip: the reference's binary PLY layout, records packed and
 // unpacked on the device.  `optimizer` (optional): the Adam moments and step count ride along as extra properties
 // m_*, v_* and a header comment (the reference's reader skips both); read_gaussian_ply restores them into

@@ -66,6 +66,10 @@ def test_cpp_adapter_matches_python_host(pkg, dev, tmp_path):
                                                                grad_threshold=2e-7), 6.0)
     ctrl.accumulate_gradients(grads.dL_dmeans_2d, out.radii)
     stats = ctrl.densify(model, 5, noise.to(dev), optimizer=opt)
+    # N4 through the C++ host equals the Python host on the same 8-bit view
+    u8 = torch.from_numpy(np.fromfile(tmp_path / "out_view_u8.bin", dtype=np.uint8).reshape(h, w, 3)).to(dev)
+    half = pkg.image_to_float(u8, w // 2, h // 2)
+    assert np.array_equal(rd("out_target_half.bin", np.uint32, (h // 2, w // 2, 3)), np_(half).view(np.uint32))
     # N3 through the C++ host: its checkpoint (with optimizer state) round-trips there, loads here, and the
     # Python writer reproduces the file byte for byte from what it loaded
     assert "ply roundtrip=1 missing_throws=1" in res.stdout
