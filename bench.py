@@ -130,6 +130,50 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     return srt.total_pairs, fwd, grads
 
 
+_PROJ_SNIPPET = r"""
+import importlib.util, json, sys, time
+import numpy as np
+root, n, w, h, deg, ncores = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); return m
+orc = load("cugs_oracle", root + "/oracle/oracle.py")
+rng = np.random.default_rng(1234)
+c = (deg + 1) ** 2
+z = rng.uniform(2, 10, n)
+pos = np.stack([rng.uniform(-1, 1, n) * z * 0.67, rng.uniform(-1, 1, n) * z * 0.38, z], 1).astype(np.float32)
+arr = dict(positions=pos, rotations=rng.standard_normal((n, 4)).astype(np.float32),
+           scales=(rng.standard_normal((n, 3)) * 0.5 - 4.6).astype(np.float32),
+           opacities=rng.standard_normal((n, 1)).astype(np.float32),
+           sh_coeffs=(0.5 * rng.standard_normal((n, 3, c))).astype(np.float32))
+R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+out = {}
+for label, th in (("mgaussians_per_s_1_thread", 1), ("mgaussians_per_s_all_cores", ncores)):
+    best = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        orc.project_sh_forward_mt(th, arr, R, t, 0.78 * w, 0.78 * w, w / 2, h / 2, w, h, deg)
+        best = min(best, time.perf_counter() - t0)
+    out[label] = round(n / best / 1e6, 2)
+print(json.dumps(out))
+"""
+
+
+def projection_cpu_baseline(wl, ncores):
+    """the per-Gaussian forward (k_project_gaussians restated + the reference's evaluate_sh_cpu loop
+    shape), single-threaded and OpenMP-parallel over Gaussians on all host cores - in a fresh interpreter without
+    torch, whose bundled OpenMP runtime otherwise shares the process with the oracle's libgomp and serialises it."""
+    import subprocess
+    try:
+        env = dict(os.environ, OMP_WAIT_POLICY="active", OMP_PROC_BIND="false")    # idle-thread wake-ups otherwise dominate
+        res = subprocess.run([sys.executable, "-c", _PROJ_SNIPPET, ROOT, str(wl.n), str(wl.width), str(wl.height),
+                              str(wl.sh_degree), str(ncores)], capture_output=True, text=True, timeout=300, env=env)
+        proj = json.loads(res.stdout.strip().splitlines()[-1])
+    except Exception as e:                          # a reported baseline must not take the benchmark down
+        proj = {"error": str(e)[:200]}
+    proj["cores"] = ncores
+    return proj
+
+
 def cpu_baseline(pkg, orc, wl, arrays, cam, g, budget_rows):
     """The oracle on host cores, single thread, on a bounded sample of the SAME workload: the full
     per-Gaussian work (projection, SH, pair sort) for all N Gaussians plus the blend forward+backward
@@ -158,7 +202,13 @@ def cpu_baseline(pkg, orc, wl, arrays, cam, g, budget_rows):
     t_nb = time.perf_counter() - t0
     nrows = rows[1] - rows[0]
     t_frame = t_n + t_nb + t_rows * wl.height / nrows
+    # the per-Gaussian forward (k_project_gaussians restated + the reference's evaluate_sh_cpu loop shape)
+    # single-threaded and OpenMP-parallel over Gaussians on all host cores of this box
+    # the GPU boxes give one GPU's job a share of 16 host CPUs; use what the process may run on, at most that
+    ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    proj = projection_cpu_baseline(wl, ncores)
     return {"value": wl.width * wl.height / t_frame / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "projection_sh_forward": proj,
             "sample": (f"oracle/cugs_oracle.c single-thread: projection+SH+sort+projection-bwd+SH-bwd of all "
                        f"{wl.n} Gaussians ({t_n + t_nb:.2f} s) + blend fwd+bwd of image rows {rows[0]}..{rows[1]} "
                        f"({t_rows:.2f} s), extrapolated x{wl.height / nrows:.2f} in rows to {wl.width}x{wl.height}"),
