@@ -363,6 +363,10 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "traffic_source": table, "algorithmic_bytes": int(alg[dom]), "ms": round(stages_ms[dom], 4)}
+            if dom in ("raster_backward", "raster_forward"):
+                roofline["note"] = ("the blend kernels are VALU-issue-bound, not HBM-bound (profiles/README.md): the backward "
+                                    "executes ~4.4 M (wave, Gaussian) steps of ~140 instructions per frame at config 3; its "
+                                    "HBM traffic alone would take ~0.1 ms")
             if dom == "sort":
                 # SURVEY 8d prices the sort as the reference does it (8 passes over 12-byte pairs: 172 B/pair); this
                 # sort moves ~45 B/pair, so the figure above can exceed the peak - it is a yardstick, not a traffic

@@ -113,6 +113,22 @@ def test_sort_predicted_capacity_path(pkg, orc, dev):
         R._last_pairs.pop(torch.device(dev), None)
 
 
+def test_render_recovers_from_a_wrong_pair_prediction(pkg, orc, dev):
+    """render() sorts on the pair count predicted from earlier frames; a scene with ten times more pairs than the
+    previous one (a new view, a densification) must come out identical through the exact-path fallback, and a
+    much smaller one through the spare capacity."""
+    R = pkg.rasterizer
+    small = _forward_both(pkg, orc, dev, 1500, 320, 240, 1, -4.0, (0.0, 0.0, 0.0), seed=5)
+    assert R._last_pairs[torch.device(dev)] < 60000
+    R._last_pairs[torch.device(dev)] = 100                       # force a gross under-prediction for the next frame
+    for n, mu_s in ((40000, -3.6), (1500, -4.0)):                # far above the prediction, then far below it
+        arrays, cam, model, settings, out, ref = _forward_both(pkg, orc, dev, n, 320, 240, 1, mu_s, (0.1, 0.2, 0.3), seed=n)
+        assert out.total_pairs == ref["total_pairs"]
+        assert np.array_equal(np_(out.gaussian_indices), ref["values"])
+        assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32))
+    assert small[4].total_pairs == small[5]["total_pairs"]
+
+
 def test_sort_equal_depth_ties_keep_index_order(pkg, orc, dev):
     """CUB's stability contract: equal (tile, depth) keys stay in ascending Gaussian index."""
     w, h, n = 128, 96, 4000
