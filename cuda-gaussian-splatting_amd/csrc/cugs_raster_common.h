@@ -65,8 +65,8 @@ __device__ __forceinline__ int stage_record(const RasterSrc& s, int li, int end,
 // alpha = min(0.99, o * exp(power)) >= 1/255 needs -power <= tau := ln(255 o)  (tau < 0: never;
 // the record stores tau = -1 for o < 1/255, where o * exp(power <= 0) <= o < 1/255 exactly).
 // -power = q/2 with q(d) = a dx^2 + 2 b dx dy + c dy^2, d = centre - mean.  Over the rectangle of
-// quad offsets the minimum of q is 0 if the mean lies inside, else it is attained on an edge;
-// along each edge q is a 1-D convex parabola (a, c > 0), minimised at the clamped vertex.
+// quad offsets the minimum of q is 0 if the mean lies inside, else it is attained on an edge facing the
+// mean; along each edge q is a 1-D convex parabola (a, c > 0), minimised at the clamped vertex.
 // Rounding: the oracle's fp32 power differs from the exact one by at most ~4 ulp of
 // B = |a| X^2 + 2 |b| X Y + |c| Y^2 (X, Y the largest |offset|); q_min here carries a similar
 // error; ocml logf ~2 ulp; detexp 1 ulp.  The slack 0.01 tau + 0.05 + 4e-6 B dominates all of it
@@ -83,16 +83,17 @@ __device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float4 r2, 
     const float X = fmaxf(fabsf(lx), fabsf(hx)), Y = fmaxf(fabsf(ly), fabsf(hy));
     const float B = a * X * X + 2.0f * fabsf(b) * X * Y + c * Y * Y;
     const float b2 = b + b;
-    // q restricted to the four edges, each at its clamped 1-D minimiser
-    const float y1 = fminf(fmaxf(-b * lx * ic, ly), hy);
-    const float y2 = fminf(fmaxf(-b * hx * ic, ly), hy);
-    const float x3 = fminf(fmaxf(-b * ly * ia, lx), hx);
-    const float x4 = fminf(fmaxf(-b * hy * ia, lx), hx);
-    const float q1 = a * lx * lx + b2 * lx * y1 + c * y1 * y1;
-    const float q2 = a * hx * hx + b2 * hx * y2 + c * y2 * y2;
-    const float q3 = a * x3 * x3 + b2 * x3 * ly + c * ly * ly;
-    const float q4 = a * x4 * x4 + b2 * x4 * hy + c * hy * hy;
-    const float qmin = inside ? 0.0f : fminf(fminf(q1, q2), fminf(q3, q4));
+    // q is convex with its minimum at the mean, so over a rectangle that does not contain the mean the minimum
+    // lies on an edge FACING the mean: the vertical edge on the mean's side if the mean is outside the x-range,
+    // the horizontal one likewise (a point of a far edge is reached from the mean through a near edge, where q
+    // is smaller).  Each at its clamped 1-D minimiser.
+    const float xe = (lx > 0.0f) ? lx : hx, ye = (ly > 0.0f) ? ly : hy;          // the near edges (if outside)
+    const float yv = fminf(fmaxf(-b * xe * ic, ly), hy);
+    const float xv = fminf(fmaxf(-b * ye * ia, lx), hx);
+    const float qx = a * xe * xe + b2 * xe * yv + c * yv * yv;
+    const float qy = a * xv * xv + b2 * xv * ye + c * ye * ye;
+    const bool out_x = !((lx <= 0.0f) && (hx >= 0.0f)), out_y = !((ly <= 0.0f) && (hy >= 0.0f));
+    const float qmin = inside ? 0.0f : fminf(out_x ? qx : 3.0e38f, out_y ? qy : 3.0e38f);
     return !(0.5f * qmin > tau * 1.01f + 0.05f + 4e-6f * B);
 }
 
