@@ -90,7 +90,8 @@ template <int C, bool ALIGNED>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int degree, CamArgs cam,
                                                                 ProjPtrs p) {
     constexpr int LROW = ShTile<C>::LROW;
-    __shared__ float s_sh[CUGS_BLOCK * LROW];
+    constexpr int OUT_F = 6 * CUGS_BLOCK + CUGS_PACKED_STRIDE * CUGS_BLOCK;      // staged outputs: rgb, cov, packed
+    __shared__ __attribute__((aligned(16))) float s_sh[CUGS_BLOCK * LROW > OUT_F ? CUGS_BLOCK * LROW : OUT_F];
 
     const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
     const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
@@ -118,7 +119,6 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
     for (int ch = 0; ch < 3; ++ch) {
         float raw = sh_colour(degree, row + ch * C, 1, dir);
         col[ch] = (raw < 0.0f) ? 0.0f : raw;
-        p.rgb[idx * 3 + ch] = col[ch];
     }
 
     // --- geometry ---
@@ -155,15 +155,42 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
         }
     }
 
-    p.means_2d[idx * 2 + 0] = mx;
-    p.means_2d[idx * 2 + 1] = my;
     p.depths[idx] = depth;
-    p.cov_2d_inv[idx * 3 + 0] = inv.a;
-    p.cov_2d_inv[idx * 3 + 1] = inv.b;
-    p.cov_2d_inv[idx * 3 + 2] = inv.c;
     p.radii[idx] = radius;
     p.tiles_touched[idx] = tiles;
     p.opacities_act[idx] = opa;
+    if (ALIGNED && count == CUGS_BLOCK && p.packed) {
+        // Full workgroup, 16-byte aligned outputs: the 12-byte-strided rgb / cov rows and the 48-byte packed
+        // records are transposed through LDS (the SH tile is dead by now) and leave as contiguous 16-byte
+        // stores - a third of the write requests of per-thread strided stores.
+        reinterpret_cast<float2*>(p.means_2d)[idx] = make_float2(mx, my);
+        __syncthreads();                                       // every thread has read its SH row
+        float* s_rgb = s_sh;
+        float* s_cov = s_sh + 3 * CUGS_BLOCK;
+        float4* s_pk = reinterpret_cast<float4*>(s_sh + 6 * CUGS_BLOCK);          // 1536 floats in: 16-byte aligned
+        const int t = threadIdx.x;
+        s_rgb[t * 3 + 0] = col[0]; s_rgb[t * 3 + 1] = col[1]; s_rgb[t * 3 + 2] = col[2];
+        s_cov[t * 3 + 0] = inv.a; s_cov[t * 3 + 1] = inv.b; s_cov[t * 3 + 2] = inv.c;
+        const float tau = (opa >= (1.0f / 255.0f)) ? logf(255.0f * opa) : -1.0f;   // as write_packed
+        s_pk[t * 3 + 0] = make_float4(mx, my, inv.a, inv.b);
+        s_pk[t * 3 + 1] = make_float4(inv.c, col[0], col[1], col[2]);
+        s_pk[t * 3 + 2] = make_float4(opa, tau, 0.0f, 0.0f);
+        __syncthreads();
+        if (t < 3 * CUGS_BLOCK / 4) {
+            reinterpret_cast<float4*>(p.rgb + base * 3)[t] = reinterpret_cast<const float4*>(s_rgb)[t];
+            reinterpret_cast<float4*>(p.cov_2d_inv + base * 3)[t] = reinterpret_cast<const float4*>(s_cov)[t];
+        }
+        float4* g_pk = reinterpret_cast<float4*>(p.packed + base * CUGS_PACKED_STRIDE);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g_pk[t + k * CUGS_BLOCK] = s_pk[t + k * CUGS_BLOCK];
+        return;
+    }
+    p.means_2d[idx * 2 + 0] = mx;
+    p.means_2d[idx * 2 + 1] = my;
+    p.rgb[idx * 3 + 0] = col[0]; p.rgb[idx * 3 + 1] = col[1]; p.rgb[idx * 3 + 2] = col[2];
+    p.cov_2d_inv[idx * 3 + 0] = inv.a;
+    p.cov_2d_inv[idx * 3 + 1] = inv.b;
+    p.cov_2d_inv[idx * 3 + 2] = inv.c;
     if (p.packed) write_packed(p.packed, idx, mx, my, inv, col[0], col[1], col[2], opa);
 }
 
@@ -263,7 +290,8 @@ extern "C" int cugs_project_forward(int64_t n, int num_coeffs, int active_degree
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
     ProjPtrs p{positions, rotations, scales, opacities, sh_coeffs, means_2d, depths, cov_2d_inv,
                radii, tiles_touched, opacities_act, rgb, packed};
-    const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rotations);
+    const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rotations) && cugs_aligned16(rgb) &&
+                         cugs_aligned16(cov_2d_inv) && (reinterpret_cast<uintptr_t>(means_2d) & 7u) == 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (num_coeffs) {
         case 1: return launch_project<1>(n, active_degree, cam, p, aligned, st);
