@@ -4,15 +4,17 @@
     python bench.py --gpus N --steps K --warmup W [--config config3] [--adam]
 
 One "step" = one pass of the hot path over one training view per GPU:
-render() + render_backward() (+ the gradient all-reduce over RCCL when N > 1, + FusedAdam.step
-with --adam / config4).  Inputs (parameters, dL_dcolor) are resident in HBM before the timed
+render() + render_backward() (+ the gradient exchange over RCCL when N > 1: --exchange compact | allreduce |
+auto, the default, which times both before the warm-up and keeps the faster; + FusedAdam.step with --adam /
+config4).  Inputs (parameters, dL_dcolor) are resident in HBM before the timed
 region.  Default workload = BASELINE.json configs[2]: 1 M synthetic Gaussians, 1920x1080, SH
 degree 3 (scene generator: cuda-gaussian-splatting_amd/scene.py).
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline      — the dominant kernel: ALGORITHMIC bytes per launch (SURVEY §8d per-unit figures x this
                   run's N, P, pixels) / its mean duration from HIP events recorded on the launch stream
-                  inside the timed region; peak = 8.0 TB/s HBM3E (MI355X_MICROARCH.md);
+                  inside the timed region (on every 4th timed step: an event between two kernels costs ~5 us
+                  of idle device); peak = 8.0 TB/s HBM3E (MI355X_MICROARCH.md);
   frame_roofline— the same for the whole fwd+bwd frame (the north-star target is stated on it);
   stages_ms     — mean per-stage durations from the same events;
   cpu_baseline  — the CPU oracle (a port of the reference's CUDA kernels; the reference has no CPU path)
