@@ -15,6 +15,9 @@
 // per-digit row scan, stable scatter with wave64 ballot ranking.  All HBM-bound integer work.
 #include "cugs_gaussian_math.h"
 
+#include <atomic>
+#include <cstdlib>
+
 namespace {
 
 constexpr int RADIX = 256;
@@ -236,12 +239,12 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(uint32_t* __rest
 // array.  NB: digit width (the match-any needs one ballot per digit bit).  NT: threads per workgroup -
 // 256 for the pair-level passes (thousands of workgroups), 1024 for the depth sort, whose 4096-item
 // chunks are too few to fill the chip with 4 waves each.
-template <typename K, bool IOTA, int NB, int NT>
+template <typename K, bool IOTA, int NB, int NT, bool ARANK>
 __global__ __launch_bounds__(NT) void k_radix_scatter(
     const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count_or_cap,
-    const unsigned long long* __restrict__ dev_count, int shift, const uint32_t* __restrict__ hist,
+    const unsigned long long* __restrict__ dev_count, int shift, uint32_t mask_rt, const uint32_t* __restrict__ hist,
     const uint32_t* __restrict__ tot, uint32_t nblk, K* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-    constexpr uint32_t mask = (1u << NB) - 1u;
+    const uint32_t mask = ARANK ? mask_rt : ((1u << NB) - 1u);       // the ballot ranking needs the width at compile time
     const uint32_t count = live_count(count_or_cap, dev_count);
     if (blockIdx.x * CHUNK >= count) return;              // chunks beyond the live items (capacity path): nothing to move
     constexpr int NW = NT / CUGS_WAVE;                    // waves
@@ -301,6 +304,18 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
         const uint32_t i = wbase + r * CUGS_WAVE + lane;
         const bool ok = i < count;
         const uint32_t d = (k[r] >> shift) & mask;
+        if constexpr (ARANK) {
+            // One LDS atomic with return per item: the hardware serves the lanes of a wave instruction that hit the
+            // same counter in ascending lane order and a wave's LDS instructions in issue order, so the returned
+            // values ARE the stable positions.  That ordering is not in the ISA manual: it is verified on the device
+            // before this path is ever selected (k_probe_lds_order), and the ballot path below stays as the fallback.
+            if (ok) {
+                const uint32_t pos = atomicAdd(&s_lbase[wave][d], 1u);
+                s_key[pos] = (K)k[r];
+                s_val[pos] = v[r];
+            }
+            continue;
+        }
         unsigned long long peers = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -520,6 +535,59 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t pairs_or_ca
     }
 }
 
+// Does an LDS atomic with return serve the lanes of one wave instruction that hit the SAME address in ascending
+// lane order, and successive instructions of a wave in issue order?  Each lane checks that the value it got back
+// equals the number of earlier (round, lane) items with its digit, for random, clustered, constant, same-bank and
+// strided digit patterns; *violations counts the mismatches.
+__device__ __forceinline__ uint32_t probe_digit(uint32_t set, uint32_t wave, uint32_t r, uint32_t lane) {
+    uint32_t h = (set * 4u + wave) * 8u + r;
+    h = (h ^ 61u) ^ (h >> 16); h *= 9u; h ^= h >> 4; h *= 0x27d4eb2du; h ^= h >> 15;
+    uint32_t x = h + lane * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    switch (set % 6u) {
+        case 0: return x & 255u;
+        case 1: return x & 127u;
+        case 2: return x & 3u;
+        case 3: return 5u;
+        case 4: return (x & 1u) ? 7u : 39u;                       // same LDS bank, 32 dwords apart
+        default: return (lane * 37u + (x & 1u)) & 63u;
+    }
+}
+__global__ __launch_bounds__(CUGS_BLOCK) void k_probe_lds_order(uint32_t* __restrict__ violations) {
+    __shared__ uint32_t cnt[4][RADIX];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, set = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < 4 * RADIX; i += CUGS_BLOCK) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t d[8], got[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = probe_digit(set, wave, r, lane);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) got[r] = atomicAdd(&cnt[wave][d[r]], 1u);
+    uint32_t bad = 0;
+    for (int r = 0; r < 8; ++r) {
+        uint32_t expect = 0;
+        for (int rr = 0; rr <= r; ++rr)
+            for (uint32_t l = 0; l < 64u && !(rr == r && l >= lane); ++l) expect += probe_digit(set, wave, rr, l) == d[r];
+        bad += expect != got[r];
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+
+// -1: not probed yet (ballot ranking is used), 0: ballot ranking, 1: atomic ranking.  CUGS_SORT_RANK=ballot|atomic
+// overrides the probe.
+std::atomic<int> g_rank_mode{-1};
+int rank_mode() {
+    int m = g_rank_mode.load(std::memory_order_relaxed);
+    if (m >= 0) return m;
+    const char* e = getenv("CUGS_SORT_RANK");
+    if (e && e[0]) {
+        m = (e[0] == 'a') ? 1 : 0;
+        g_rank_mode.store(m, std::memory_order_relaxed);
+        return m;
+    }
+    return -1;
+}
+
 template <typename K, bool IOTA, int NT>
 int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned long long* dev_count, int shift, int bits,
                uint32_t* hist, uint32_t* tot, K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st) {
@@ -531,9 +599,15 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
     }
     hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, hist, nblk, tot);
     CUGS_LAUNCH_CHECK();
+    if (rank_mode() == 1) {               // digit width only matters to the ballot ranking: one instantiation
+        hipLaunchKernelGGL((k_radix_scatter<K, IOTA, 8, NT, true>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count,
+                           shift, (1u << bits) - 1u, hist, tot, nblk, kout, vout);
+        CUGS_LAUNCH_CHECK();
+        return 0;
+    }
 #define CUGS_SCATTER(NB)                                                                                          \
-    hipLaunchKernelGGL((k_radix_scatter<K, IOTA, NB, NT>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count, \
-                       shift, hist, tot, nblk, kout, vout)
+    hipLaunchKernelGGL((k_radix_scatter<K, IOTA, NB, NT, false>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count, \
+                       shift, 0u, hist, tot, nblk, kout, vout)
     switch (bits) {
         case 1: CUGS_SCATTER(1); break;
         case 2: CUGS_SCATTER(2); break;
@@ -650,9 +724,20 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const flo
     if (ntx > 32767 || nty > 32767) return CUGS_EOVERFLOW;          // rectangle extents travel as 16-bit halves
     int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st);
     if (rc) return rc;
+    // first blocking sort of the process: verify the LDS ordering the atomic ranking relies on (64 workgroups, once)
+    const bool probing = rank_mode() < 0;
+    uint32_t* probe_word = reinterpret_cast<uint32_t*>(ws.total) + 8;
+    uint32_t violations = 1;
+    if (probing) {
+        CUGS_RETURN_IF_HIP(hipMemsetAsync(probe_word, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_probe_lds_order, dim3(96), dim3(CUGS_BLOCK), 0, st, probe_word);
+        CUGS_LAUNCH_CHECK();
+        CUGS_RETURN_IF_HIP(hipMemcpyAsync(&violations, probe_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
     // straight into the caller's variable: if that is pinned host memory the copy is one DMA, no staging
     CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     CUGS_RETURN_IF_HIP(hipStreamSynchronize(st));
+    if (probing) g_rank_mode.store(violations == 0 ? 1 : 0, std::memory_order_relaxed);
     if ((unsigned long long)*total_pairs_host > 2147483647ull) {   // the reference indexes pairs with int
         *total_pairs_host = 0;
         return CUGS_EOVERFLOW;
@@ -729,3 +814,11 @@ extern "C" int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const floa
                                width, height, ntx, nty, keys_sorted, values_sorted, tile_ranges,
                                static_cast<const unsigned long long*>(ws.total), st);
 }
+
+// Debug hook (not part of the ABI header): force (0 = ballot, 1 = atomic) or query (-2) the ranking mode of the
+// radix scatter; returns the mode in effect (-1 = not probed yet).
+extern "C" int cugsdbg_sort_rank_mode(int mode) {
+    if (mode == 0 || mode == 1 || mode == -1) g_rank_mode.store(mode, std::memory_order_relaxed);
+    return g_rank_mode.load(std::memory_order_relaxed);
+}
+

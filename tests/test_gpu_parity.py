@@ -77,6 +77,32 @@ def test_sort_parity_bit_exact(pkg, orc, dev, n, w, h, mu_s):
     assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])                          # per-tile spans
 
 
+def test_sort_ranking_modes_agree_and_probe_selects_one(pkg, orc, dev):
+    """The radix scatter ranks either with wave ballots (match-any) or with one LDS atomic-with-return per item,
+    which relies on the LDS serving same-address lanes in lane order - verified on the device by a probe before
+    it is ever used.  Both must give the oracle's order; the probe must have settled on a mode by now."""
+    import ctypes as C
+    from cugs_amd._lib import lib
+    fn = lib.cugsdbg_sort_rank_mode
+    fn.restype, fn.argtypes = C.c_int, [C.c_int]
+    n, w, h = 60000, 1280, 720
+    arrays, cam = _scene(pkg, n, w, h, 0, seed=8, mu_s=-4.0)
+    ref = oracle_forward(orc, arrays, cam, degree=0)
+    t = lambda k: torch.from_numpy(ref[k]).to(dev)
+    pkg.sort_gaussians(t("means_2d"), t("depths"), t("radii"), t("tiles_touched"), w, h)     # triggers the probe if needed
+    chosen = fn(-2)
+    assert chosen in (0, 1)
+    try:
+        for mode in (0, 1):
+            assert fn(mode) == mode
+            srt = pkg.sort_gaussians(t("means_2d"), t("depths"), t("radii"), t("tiles_touched"), w, h)
+            assert np.array_equal(np_(srt.gaussian_keys_sorted).view(np.uint64), ref["keys"]), mode
+            assert np.array_equal(np_(srt.gaussian_values_sorted), ref["values"]), mode
+            assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"]), mode
+    finally:
+        fn(chosen)
+
+
 def test_sort_predicted_capacity_path(pkg, orc, dev):
     """cugs_sort_pairs_predicted: same result as the exact two-call path when the capacity suffices (also with
     keys and with spare capacity), a detectable miss when it does not, and a clean empty case."""
