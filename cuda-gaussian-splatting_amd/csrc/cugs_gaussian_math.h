@@ -16,6 +16,23 @@ struct Sym3 { float xx, xy, xz, yy, yz, zz; };         // upper triangle
 struct M3 { float m00, m01, m02, m10, m11, m12, m20, m21, m22; };   // row-major
 struct M23 { float r0x, r0y, r0z, r1x, r1y, r1z; };    // 2x3, row-major
 
+// The blend backward (raster_backward.hip) accumulates, per Gaussian, the moments of dL/dpower over the pixel
+// offsets d = pixel centre - mean:  M1 = sum dpw d,  M2 = sum dpw (dx^2, dx dy, dy^2).  With power = -q/2,
+// q = d^T Sigma'^-1 d (backward.cu:200-213):
+//   dL/dmean2d = sum dpw * Sigma'^-1 d = Sigma'^-1 M1                      (backward.cu:203-204)
+//   dL/dSigma'^-1 = (-M2xx/2, -M2xy [combined off-diagonal, Q3], -M2yy/2)   (backward.cu:209-213)
+struct GradMoments { float m1x, m1y, m2xx, m2xy, m2yy; };
+struct Grad2D { float mx, my, a, b, c; };
+__device__ __forceinline__ Grad2D grads_from_moments(const GradMoments& m, float a, float b, float c) {
+    Grad2D g;
+    g.mx = a * m.m1x + b * m.m1y;
+    g.my = b * m.m1x + c * m.m1y;
+    g.a = -0.5f * m.m2xx;
+    g.b = -m.m2xy;
+    g.c = -0.5f * m.m2yy;
+    return g;
+}
+
 __device__ __forceinline__ M3 view_rotation(const CamArgs& c) {
     return M3{c.view[0], c.view[1], c.view[2], c.view[4], c.view[5], c.view[6],
               c.view[8], c.view[9], c.view[10]};

@@ -128,8 +128,9 @@ __device__ __forceinline__ ActiveRect active_rect(unsigned long long active, flo
 //   * open == 0 -> alpha = 0 < 1/255 -> skipped.
 // Returns alpha if the Gaussian passes at this pixel, else exactly 0.
 struct PixelEval { float dx, dy, gx, gy, e; };
-__device__ __forceinline__ float pixel_alpha(float pxf, float pyf, float mx, float my, float a, float b,
-                                             float c, float o, float open, PixelEval& r) {
+// min(0.99, o e^power) with the power > 0 skip and the open flag folded in, BEFORE the alpha >= 1/255 test.
+__device__ __forceinline__ float pixel_alpha_raw(float pxf, float pyf, float mx, float my, float a, float b,
+                                                 float c, float o, float open, PixelEval& r) {
     r.dx = pxf - mx;
     r.dy = pyf - my;
     r.gx = fmaf(a, r.dx, b * r.dy);
@@ -138,69 +139,112 @@ __device__ __forceinline__ float pixel_alpha(float pxf, float pyf, float mx, flo
     float pw = fmaxf(power, -6.0f);
     pw = (power > 0.0f) ? -6.0f : pw;
     r.e = cugs_expf_small(pw);                                // pw in [-6, 0]: same bits as cugs_expf
-    const float alpha = fminf((o * open) * r.e, 0.99f);       // o * 1.0f is exact
+    return fminf((o * open) * r.e, 0.99f);                    // o * 1.0f is exact
+}
+__device__ __forceinline__ float pixel_alpha(float pxf, float pyf, float mx, float my, float a, float b,
+                                             float c, float o, float open, PixelEval& r) {
+    const float alpha = pixel_alpha_raw(pxf, pyf, mx, my, a, b, c, o, open, r);
     return (alpha < (1.0f / 255.0f)) ? 0.0f : alpha;
 }
 
 // ---------------------------------------------------------------------------------------
-// reduce9: sums NINE per-lane values across the 64 lanes of a wave and leaves each total in a
-// different lane (33 VALU-class operations instead of 9 x 6 DPP adds + a 9-way select).
-//
-// "Transpose-reduce": at every halving step two partner lanes exchange the half of the values they
-// will not keep (`keep = side ? b : a; give = side ? a : b; keep + dpp(give)`), so the number of live
-// values per lane halves as the number of lanes sharing a sum doubles.  Inside each 16-lane row the
-// partners / sides are
-//   row_mirror (i <-> 15-i, side = bit3), row_half_mirror (i <-> i^7, side = bit2),
-//   quad_perm[3,2,1,0] (i <-> i^3, side = bit1), quad_perm[1,0,3,2] (i <-> i^1, side = bit0)
-// (before each step both partners hold the same set of values: their higher side bits agree); live
-// values 9 -> 5 -> 3 -> 2 -> 1.  The four row totals of the single remaining value are then combined
-// with gfx950's v_permlane16_swap / v_permlane32_swap (x = t, y = t; swap; x + y), which measured
-// markedly cheaper than doing the two cross-row halvings first on nine values (8 swaps).
-// All 64 lanes must be active (EXEC full): callers run it in wave-uniform control flow with zeros in
-// lanes that have nothing to add.
-//
-// Result: lane L (any row; i = L & 15) returns the WAVE total of slot reduce9_slot(L):
-//   i even: slot 4*bit1 + 2*bit2 + bit3  (i = 0,8,4,12,2,10,6,14 -> slots 0..7);  i == 1: slot 8;
-//   only row 0's lanes are designated to deliver.
-//
-// The swaps are issued through inline asm: with ROCm 7.2's hipcc the two results of
-// __builtin_amdgcn_permlane{16,32}_swap collapse into one register when both feed the same add
-// (observed: `v_permlane32_swap v2, v3 ; v_add_f32 v2, v2, v2`).  hipcc pads nothing inside an asm
-// statement, so the 2 wait states it otherwise inserts between a VALU write and a swap that reads
-// the register (s_nop 1) are part of the string.
+// Cost model behind the choices below (tools/microbench/valu_rate.hip on MI355X, 8 waves per SIMD,
+// chip-wide wave-instructions per second, plain fma/mul/add = 1 unit):
+//   v_fma/v_mul/v_add/v_mov (also with `clamp`)  950 G/s   1.0      v_max/v_min/v_med3            585 G/s  1.6
+//   DPP add (any control, any bank mask)       560-590     1.6-1.7  v_cmp (vcc or sgpr pair)      560     1.7
+//   v_cndmask (sgpr mask)                        518       1.85     v_rcp/v_exp, v_permlane*_swap 300     3.2
+// The blend kernels are bound by this issue rate, so per-lane decisions are kept as 0/1 FLOATS produced by
+// `v_fma ... clamp` and multiplied in (1 unit each) instead of v_cmp + v_cndmask (3.55 units a pair), and the
+// wave reduction avoids v_cndmask altogether.
 // ---------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+
+// saturate(a*b + c) in one instruction (v_fma_f32 ... clamp).
+__device__ __forceinline__ float sat_fma(float a, float b, float c) {
+    return __builtin_amdgcn_fmed3f(fmaf(a, b, c), 0.0f, 1.0f);
 }
-template <int CTRL>
-__device__ __forceinline__ float xchg_add(bool side, float a, float b) {
-    return (side ? b : a) + dpp_mov<CTRL>(side ? a : b);
+__device__ __forceinline__ float sat_add(float a, float b) { return __builtin_amdgcn_fmed3f(a + b, 0.0f, 1.0f); }
+
+// 1.0f if x >= 1/255 (the reference's `alpha < 1/255 -> skip`, forward.cu:141 / backward.cu:137) else 0.0f, exactly,
+// for every non-NaN x <= 2^31: with p = the float just below 1/255, x >= 1/255 <=> x > p <=> x - p >= ulp = 2^-31.
+// The fma rounds (x - p) * 2^32 once: >= 2 when x passes, <= 0 when it does not.  NaN -> 0 (dx10 clamp).
+#define CUGS_ALPHA_MIN_PRED 0x1.01010p-8f      /* 0x3B808080: pred(1.0f/255.0f), 1/255 = 0x3B808081 */
+__device__ __forceinline__ float passes_alpha_min(float x) {
+    return sat_fma(x, 0x1p32f, -CUGS_ALPHA_MIN_PRED * 0x1p32f);
+}
+// 1.0f if x < 0.99f else 0.0f (x <= 0.99f always here): 0.99f - x >= ulp(0.5..1) = 2^-24.
+__device__ __forceinline__ float below_alpha_cap(float x) { return sat_fma(x, -0x1p32f, 0.99f * 0x1p32f); }
+
+// ---------------------------------------------------------------------------------------
+// reduce9t: sums NINE per-lane values across the 64 lanes of a wave and leaves each total in a different
+// lane ("transpose-reduce": at every halving step two partner lanes exchange the half of the values they
+// will not keep, so the number of live values halves as the number of lanes sharing a sum doubles),
+// without a single v_cndmask:
+//   stage 1  row_mirror (i <-> 15-i, side = lane bit 3 = banks {0,1} | {2,3}):  9 -> 5 values.
+//            The "keep mine / give the other" selection is the DPP BANK MASK: `x + dpp(x)` written to banks
+//            0,1 from one register and to banks 2,3 from the other (two DPP adds per pair, 3.4 units instead of
+//            two selects + one DPP add, 5.3).  The first pair needs no selection at all: the caller hands it
+//            over already swizzled (cA holds value 0 in side-0 lanes and value 1 in side-1 lanes, cB the
+//            opposite - for the blend backward these are dL/dcolour products whose per-lane factor is
+//            swizzled once per kernel), so it is ONE DPP add.
+//   stage 2  row_half_mirror (i <-> i^7, side = lane bit 2 = banks {0,2} | {1,3}):  5 -> 3, same trick.
+//   stage 3  v_permlane16_swap (rows 0<->1, 2<->3): swaps odd rows of x with even rows of y, so x + y is the
+//            transposed pair sum with no selection: 3 -> 2 (the odd value is summed with a copy of itself).
+//   stage 4  v_permlane32_swap (halves): 2 -> 1.
+//   stages 5, 6  the four lanes of each bank still hold partial sums of the same value: two quad_perm adds.
+// 13 DPP adds + 3 swaps + 5 plain = ~37 units (the select-based version: 57).  All 64 lanes must be active.
+//
+// Result: lane L returns the WAVE total of slot reduce9t_slot(L); within rows 0..2 every lane of a bank holds
+// the same total, the first lane of each bank is designated to deliver:
+//   row 0: banks 0..3 -> slots 0, 2, 1, 3;  row 1: banks 0..3 -> slots 4, 6, 5, 8;  row 2: slot 7.
+// Slot k is the k-th value in the argument order (v0 v1 | v2 v3 | v4 v5 | v6 v8 | v7), where the caller passes
+// v0/v1 swizzled as described.
+//
+// Hand-scheduled inline asm: hipcc pads nothing inside an asm statement, so the wait states gfx950 needs
+// between a VALU write and a DPP / permlane read of the same register (2) are s_nops in the string; the
+// instruction order keeps producers and DPP consumers at least two instructions apart elsewhere.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int reduce9t_slot(int lane) {
+    if (lane & 3) return -1;
+    const int bank = (lane >> 2) & 3, row = lane >> 4;
+    const int perm[4] = {0, 2, 1, 3};
+    if (row == 0) return perm[bank];
+    if (row == 1) return bank == 3 ? 8 : 4 + perm[bank];
+    if (row == 2 && bank == 0) return 7;
+    return -1;
 }
 
-__device__ __forceinline__ int reduce9_slot(int lane) {
-    const int li = lane & 15;
-    if (lane >= 16) return -1;
-    if (li == 1) return 8;
-    if (li & 1) return -1;
-    return ((li >> 1) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 3) & 1);
-}
-
-__device__ __forceinline__ float reduce9(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
-                                         float v7, float v8, int lane) {
-    const bool s3 = (lane & 8) != 0, s2 = (lane & 4) != 0, s1 = (lane & 2) != 0, s0 = (lane & 1) != 0;
-    const float a0 = xchg_add<0x140>(s3, v0, v1), a1 = xchg_add<0x140>(s3, v2, v3);      // row_mirror
-    const float a2 = xchg_add<0x140>(s3, v4, v5), a3 = xchg_add<0x140>(s3, v6, v7);
-    const float a4 = v8 + dpp_mov<0x140>(v8);
-    const float b0 = xchg_add<0x141>(s2, a0, a1), b1 = xchg_add<0x141>(s2, a2, a3);      // row_half_mirror
-    const float b2 = a4 + dpp_mov<0x141>(a4);
-    const float c0 = xchg_add<0x1B>(s1, b0, b1);                                         // quad_perm [3,2,1,0]
-    const float c1 = b2 + dpp_mov<0x1B>(b2);
-    float x = xchg_add<0xB1>(s0, c0, c1);                                                // quad_perm [1,0,3,2]
-    float y = x;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));         // rows 0+1, 2+3
-    x += y;
-    y = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));         // halves
-    return x + y;
+__device__ __forceinline__ float reduce9t(float cA, float cB, float v2, float v3, float v4, float v5, float v6,
+                                          float v8, float v7) {
+    float a0, a1, a2, a3, a4, b0, b1, b2, d;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %10, %9 row_mirror row_mask:0xf bank_mask:0xf\n\t"       // a0 = cA + mirror(cB)
+        "v_add_f32_dpp %1, %11, %11 row_mirror row_mask:0xf bank_mask:0x3\n\t"      // a1 = v2 + mirror(v2) | v3 + mirror(v3)
+        "v_add_f32_dpp %1, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %13, %13 row_mirror row_mask:0xf bank_mask:0x3\n\t"      // a2 = v4 | v5
+        "v_add_f32_dpp %2, %14, %14 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %15, %15 row_mirror row_mask:0xf bank_mask:0x3\n\t"      // a3 = v6 | v8
+        "v_add_f32_dpp %3, %16, %16 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %17, %17 row_mirror row_mask:0xf bank_mask:0xf\n\t"      // a4 = v7
+        "v_add_f32_dpp %5, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   // b0 = a0 | a1
+        "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"   // b2 = a4
+        "v_add_f32_dpp %6, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   // b1 = a2 | a3
+        "v_add_f32_dpp %6, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_mov_b32 %8, %7\n\t"                                                      // d = copy of b2
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %5, %6\n\t"                                          // rows: (b0,b1) transposed
+        "v_permlane16_swap_b32 %7, %8\n\t"
+        "v_add_f32 %5, %5, %6\n\t"                                                  // c0
+        "v_add_f32 %7, %7, %8\n\t"                                                  // c1
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %5, %7\n\t"                                          // halves: (c0,c1) transposed
+        "v_add_f32 %8, %5, %7\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(d)
+        : "v"(cA), "v"(cB), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v8), "v"(v7));
+    return d;
 }

@@ -223,15 +223,16 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     V3 pos{0.0f, 0.0f, 0.0f};
     float g_mx = 0.0f, g_my = 0.0f, g_opa = 0.0f;
     Sym2 g_inv{0.0f, 0.0f, 0.0f};
+    GradMoments mom{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};            // grad_accum rows carry moments (raster_backward.hip)
+    const bool from_rows = (p.grad_accum != nullptr);         // kernel-uniform
     if (live) {
         pos = V3{p.positions[idx * 3 + 0], p.positions[idx * 3 + 1], p.positions[idx * 3 + 2]};
         float g_rgb[3];
-        if (p.grad_accum) {
+        if (from_rows) {
             const float4* row = reinterpret_cast<const float4*>(p.grad_accum + idx * CUGS_GRAD_STRIDE);
             const float4 r0 = row[0], r1 = row[1];
             g_rgb[0] = r0.x; g_rgb[1] = r0.y; g_rgb[2] = r0.z; g_opa = r0.w;
-            g_mx = r1.x; g_my = r1.y; g_inv.a = r1.z; g_inv.b = r1.w;
-            g_inv.c = p.grad_accum[idx * CUGS_GRAD_STRIDE + 8];
+            mom = GradMoments{r1.x, r1.y, r1.z, r1.w, p.grad_accum[idx * CUGS_GRAD_STRIDE + 8]};
         } else {
             g_rgb[0] = p.g_rgb[idx * 3 + 0]; g_rgb[1] = p.g_rgb[idx * 3 + 1]; g_rgb[2] = p.g_rgb[idx * 3 + 2];
             g_opa = p.g_opa[idx];
@@ -282,6 +283,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
         const Sym2 cov = screen_covariance(project_matrix_full(J, W), S);
         Sym2 inv;
         if (invert_sym2(cov, inv) > 0.0f) {                    // projection_backward.cu:91
+            if (from_rows) {                                   // a Gaussian with a non-zero row passed this test in the forward
+                const Grad2D g2 = grads_from_moments(mom, inv.a, inv.b, inv.c);
+                g_mx = g2.mx; g_my = g2.my;
+                g_inv = Sym2{g2.a, g2.b, g2.c};
+            }
             const M23 T = project_matrix_sparse(J, W);
             const Sym2 g_cov = grad_cov_from_inv(inv, g_inv);
             const Sym3 g_S = grad_cov3d(T, g_cov);

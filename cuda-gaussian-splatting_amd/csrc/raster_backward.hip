@@ -4,34 +4,44 @@
 // its four zero-fills (backward.cu:259-262).  Reference quirks kept:
 //   Q1 contributors are COUNTED from the end of the tile list; the walk stops once the count
 //      exceeds the forward's n_contrib (backward.cu:140-145);
-//   Q2 T /= max(1-alpha, 1e-5) (:150-151); a clamped alpha (o e^power >= 0.99) zeroes dL/do and
-//      dL/dpower but dL/drgb still flows (:181-191);
+//   Q2 T /= max(1-alpha, 1e-5) (:150-151; alpha <= 0.99 makes the max a no-op); a clamped alpha
+//      (o e^power >= 0.99) zeroes dL/do and dL/dpower but dL/drgb still flows (:181-191);
 //   Q3 dL/db is the combined off-diagonal derivative -dx dy (:211).
 //
 // What is different from the reference is the scatter.  The reference issues nine float atomics
 // per (pixel, Gaussian) contribution (backward.cu:217-228).  Here all 64 pixels of a wave look at
 // the same Gaussian in the same step, so the nine partials are first summed across the wave
-// (reduce9, cugs_raster_common.h: 27 operations, each total landing in a different lane) and then
-// leave the wave as ONE atomic wave-instruction whose nine active lanes hit nine consecutive floats
-// of the Gaussian's 64-byte-aligned accumulator row - a single memory-side request
-// (MI355X_MICROARCH.md, Global float atomics).  Measured (profiles/r01 ablation): the atomics are
-// free next to the evaluation; an earlier LDS stage that merged the four waves of a tile first cost
-// more in zero/flush/barrier overhead than it saved in requests.
+// (reduce9t, cugs_raster_common.h) and then leave the wave as ONE atomic wave-instruction whose nine
+// active lanes hit nine consecutive floats of the Gaussian's 64-byte-aligned accumulator row - a
+// single memory-side request (MI355X_MICROARCH.md, Global float atomics).
+//
+// The kernel is bound by VALU issue (profiles/README.md), so the step is written for instruction
+// count, priced with the measured costs in cugs_raster_common.h:
+//   * every per-lane decision is a 0/1 float made by `v_fma ... clamp` and multiplied in: no v_cmp /
+//     v_cndmask pairs.  The Q1 counter is `rem` = n_contrib - passers so far, `open` = sat(rem + 1);
+//   * the colour accumulators S_c (backward.cu:83-87, 196-198) only ever enter as sum_c dL/dC_c S_c:
+//     that ONE dot product D is carried instead (D += weight * G, G = sum_c dL/dC_c c_c);
+//   * the five geometric gradients are accumulated as the MOMENTS of dL/dpower over the pixel offsets,
+//     M1 = sum dpw (dx, dy), M2 = sum dpw (dx^2, dx dy, dy^2) - two products fewer per step than
+//     dpw * (a dx + b dy) etc.; the per-Gaussian linear map to dL/dmean2d = Sigma'^-1 M1 and
+//     dL/dSigma'^-1 = (-M2xx/2, -M2xy, -M2yy/2) is applied once per Gaussian by the consumer
+//     (k_project_backward / k_unpack_grads).  Accumulator row: {drgb[3], dopa, M1x, M1y, M2xx, M2xy, M2yy};
+//   * T *= rcp(1 - al) needs no "did it contribute" select: v_rcp_f32(1.0f) is exactly 1.0f
+//     (tests/test_gpu_reduce9.py checks it on the device).
 // The summation order differs from any sequential order; the oracle accumulates in fp64.
 // Per-contribution VALUES (not decisions) use v_rcp_f32 and fused multiply-adds: 1 ulp-level
 // differences from the oracle's divisions, far inside the 1e-4 bar.
 #include "cugs_raster_common.h"
 
-#include <stdlib.h>
+#ifdef CUGS_DEV
+bool cugs_dev_backward_stats();
+#endif
 
 namespace {
 
-
-
-// ABL: 0 = product; 1..3 = timing-only ablations selected by CUGS_BWD_ABLATE (tools/ablate_backward.py):
-// 1 no wave reduction, 2 no global atomics, 3 no per-pixel evaluation, 4 = product + step counters written to
-// accumulator row n (the tool allocates n+1 rows).  Outputs are wrong for ABL 1..3.
-template <bool PACKED, int ABL>
+// WIDE: accumulator larger than 4 GiB (n > 2^26 rows): 64-bit scatter addresses.
+// STATS (dev builds only): step counters written to accumulator row `stats_row` (tools/ablate_backward.py).
+template <bool PACKED, bool WIDE, bool STATS>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, RasterSrc src,
                                                                 const float* __restrict__ dL_dcolor,
                                                                 const float* __restrict__ final_T,
@@ -63,14 +73,20 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         dC1 = dL_dcolor[pix * 3 + 1];
         dC2 = dL_dcolor[pix * 3 + 2];
     }
-    float S0 = T * geo.bg0, S1 = T * geo.bg1, S2 = T * geo.bg2;      // backward.cu:83-87
-    int found = 0;
-    // A pixel with n_contrib == 0 stops at its first passing Gaussian without contributing
-    // (backward.cu:141-145), so it can start out finished.  `open`: 1 while the pixel is still walking.
+    // reduce9t's first pair arrives swizzled: red's product in side-0 lanes (lane bit 3 clear), green's in side-1
+    const bool side = (lane & 8) != 0;
+    const float dCA = side ? dC1 : dC0, dCB = side ? dC0 : dC1;
+    // D = sum_c dL/dC_c * (colour accumulated behind the current Gaussian), starting from the background
+    float D = fmaf(dC2, T * geo.bg2, fmaf(dC1, T * geo.bg1, dC0 * (T * geo.bg0)));      // backward.cu:83-87
+    // rem = n_contrib - (passing Gaussians seen so far, counted from the END: Q1).  A pixel stops - without
+    // contributing - at the passer that takes rem below zero (backward.cu:141-145); a pixel with
+    // n_contrib == 0, or outside the image, starts out finished.  open == sat(rem + 1) throughout.
+    float rem = (inside && max_contrib > 0) ? (float)max_contrib : -1.0f;
     float open = (inside && max_contrib > 0) ? 1.0f : 0.0f;
     bool wave_done = (__ballot(open != 0.0f) == 0ull);
-    const int my_slot = reduce9_slot(lane);
-    unsigned st_steps = 0, st_contrib = 0, st_lanes = 0, st_batches = 0, st_tested = 0, st_open = 0;   // ABL == 4 only
+    const int my_slot = reduce9t_slot(lane);
+    const unsigned slot_off = (unsigned)(my_slot < 0 ? 0 : my_slot) * 4u;
+    unsigned st_steps = 0, st_contrib = 0, st_lanes = 0, st_batches = 0, st_tested = 0, st_open = 0;   // STATS only
 
     for (int batch = num_batches - 1; batch >= 0; --batch) {
         if (lane == 0) s_wave_done[wave] = wave_done ? 1 : 0;
@@ -80,7 +96,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         stage_record<PACKED>(src, range_start + batch * CUGS_BLOCK + tid, range_end, s_rec);
         __syncthreads();
 
-        if (ABL == 4 && !wave_done) ++st_batches;
+        if (STATS && !wave_done) ++st_batches;
         if (!wave_done) {
             const int batch_count = min(CUGS_BLOCK, num_in_range - batch * CUGS_BLOCK);
             const int nsub = (batch_count + CUGS_WAVE - 1) / CUGS_WAVE;
@@ -92,55 +108,51 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                     hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1],
                                          s_rec[j * CUGS_REC_F4 + 2], ar.x0, ar.y0, ar.wx, ar.wy);
                 unsigned long long mask = __ballot(hit);
-                if (ABL == 4) st_tested += min(CUGS_WAVE, batch_count - sub * CUGS_WAVE);
+                if (STATS) st_tested += min(CUGS_WAVE, batch_count - sub * CUGS_WAVE);
                 while (mask != 0ull) {                                     // back to front: highest bit first
-                    if (ABL == 4) ++st_steps;
+                    if (STATS) ++st_steps;
                     const int bit = 63 - __builtin_clzll(mask);
                     mask &= ~(1ull << bit);
                     const float4* rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
                     const float4 g0 = rp[0], g1 = rp[1], g2 = rp[2];
-                    const float a = g0.z, b = g0.w, c = g1.x, o = g2.x;
 
-                    // ---- decisions (backward.cu:123-145), all in vector registers: see pixel_alpha()
+                    // ---- decisions (backward.cu:123-145) as 0/1 floats
                     PixelEval e;
-                    const float alpha_p = (ABL == 3) ? 0.0f : pixel_alpha(pxf, pyf, g0.x, g0.y, a, b, c, o, open, e);
-                    found += (alpha_p != 0.0f) ? 1 : 0;                    // contributors counted from the END (Q1)
-                    const float al = (found <= max_contrib) ? alpha_p : 0.0f;
-                    open = (alpha_p != al) ? 0.0f : open;                  // passed, but beyond n_contrib: finished
+                    const float alpha = pixel_alpha_raw(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g2.x, open, e);
+                    const float passf = passes_alpha_min(alpha);           // alpha >= 1/255 (0 for a finished pixel)
+                    rem -= passf;                                          // contributors counted from the END (Q1)
+                    open = sat_add(rem, 1.0f);                             // 0 once a passer fell beyond n_contrib
+                    const float k = passf * open;                          // 1: this Gaussian contributes here
+                    const float al = alpha * k;
+                    // clamp gate (backward.cu:181-191): o e >= 0.99 <=> alpha == 0.99f zeroes dL/do and dL/dpower,
+                    // dL/drgb still flows
+                    const float gk = k * below_alpha_cap(alpha);
 
-                    // ---- values (v_rcp_f32 + FMAs); al == 0 makes every sum below exactly zero
-                    const bool live = (al != 0.0f);
-                    const float rcp = __builtin_amdgcn_rcpf(fmaxf(1.0f - al, 1e-5f));
-                    T = live ? T * rcp : T;                                // T_before = T_after / (1 - alpha)
+                    // ---- values (v_rcp_f32 + FMAs); k == 0 makes every sum below exactly zero
+                    const float rcp = __builtin_amdgcn_rcpf(1.0f - al);    // al <= 0.99; rcp(1) == 1 exactly
+                    T *= rcp;                                              // T_before = T_after / (1 - alpha)
                     const float weight = al * T;
-                    float v0 = dC0 * weight, v1 = dC1 * weight, v2 = dC2 * weight;
-                    float dL_dalpha = dC0 * fmaf(T, g1.y, -S0 * rcp);
-                    dL_dalpha = fmaf(dC1, fmaf(T, g1.z, -S1 * rcp), dL_dalpha);
-                    dL_dalpha = fmaf(dC2, fmaf(T, g1.w, -S2 * rcp), dL_dalpha);
-                    S0 = fmaf(weight, g1.y, S0);
-                    S1 = fmaf(weight, g1.z, S1);
-                    S2 = fmaf(weight, g1.w, S2);
-                    // clamp gate (backward.cu:181-191): o e >= 0.99 zeroes dL/do and dL/dpower, dL/drgb still flows
-                    const float gate = (o * e.e >= 0.99f) ? 0.0f : dL_dalpha;
-                    float v3 = live ? gate * e.e : 0.0f;
-                    const float dpw = gate * al;                           // dL/dpower
-                    float v4 = dpw * e.gx, v5 = dpw * e.gy;
-                    const float hdp = -0.5f * dpw;
-                    float v6 = hdp * e.dx * e.dx, v7 = -dpw * e.dx * e.dy, v8 = hdp * e.dy * e.dy;
-                    if (ABL == 4) {
-                        const unsigned long long lm = __ballot(live);
+                    const float G = fmaf(dC2, g1.w, fmaf(dC1, g1.z, dC0 * g1.y));
+                    const float gate = fmaf(T, G, -(rcp * D)) * gk;        // dL/dalpha, gated
+                    D = fmaf(weight, G, D);
+                    const float v3 = gate * e.e;                           // dL/dopacity_act
+                    const float dpw = gate * alpha;                        // dL/dpower
+                    const float t1 = dpw * e.dx, t2 = dpw * e.dy;          // first moments
+                    const float mxx = t1 * e.dx, mxy = t1 * e.dy, myy = t2 * e.dy;
+                    if (STATS) {
+                        const unsigned long long lm = __ballot(k != 0.0f);
                         if (lm) { ++st_contrib; st_lanes += __popcll(lm); st_open += __popcll(__ballot(open != 0.0f)); }
                     }
                     // Every step reduces and adds (93% of steps contribute; an all-zero add is harmless and
                     // cheaper than the scalar test-and-branch that would skip it).
-                    if (ABL == 1) {
-                        asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8));
-                    } else {
-                        const float total = reduce9(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
-                        if (ABL == 2) {
-                            asm volatile("" ::"v"(total));
-                        } else if (my_slot >= 0) {
-                            atomicAdd(&grad_accum[(int64_t)__float_as_int(g2.z) * CUGS_GRAD_STRIDE + my_slot], total);
+                    const float total = reduce9t(dCA * weight, dCB * weight, dC2 * weight, v3, t1, t2, mxx, myy, mxy);
+                    if (my_slot >= 0) {
+                        const int g = __float_as_int(g2.z);
+                        if (WIDE) {
+                            atomicAdd(grad_accum + (int64_t)g * CUGS_GRAD_STRIDE + my_slot, total);
+                        } else {
+                            const unsigned off = ((unsigned)g << 6) + slot_off;     // row bytes = 4 * CUGS_GRAD_STRIDE = 64
+                            atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(grad_accum) + off), total);
                         }
                     }
                     if (__ballot(open != 0.0f) == 0ull) { wave_done = true; break; }
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         }
         // the next iteration's first barrier orders this batch's LDS reads before the re-staging
     }
-    if (ABL == 4 && lane == 0) {
+    if (STATS && lane == 0) {
         float* st = grad_accum + (int64_t)stats_row * CUGS_GRAD_STRIDE;
         atomicAdd(&st[0], (float)st_steps); atomicAdd(&st[1], (float)st_contrib); atomicAdd(&st[2], (float)st_lanes);
         atomicAdd(&st[3], (float)st_batches); atomicAdd(&st[4], (float)st_tested); atomicAdd(&st[5], (float)num_batches);
@@ -157,8 +169,12 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     }
 }
 
-// grad_accum rows -> the four reference-layout tensors of RasterizeBackwardOutput (backward.hpp).
+// grad_accum rows -> the four reference-layout tensors of RasterizeBackwardOutput (backward.hpp); applies the
+// per-Gaussian map from the accumulated moments (see the header comment) with Sigma'^-1 = (a, b, c).
+template <bool PACKED>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_unpack_grads(int64_t n, const float* __restrict__ acc,
+                                                             const float* __restrict__ packed,
+                                                             const float* __restrict__ cov_2d_inv,
                                                              float* __restrict__ dL_drgb,
                                                              float* __restrict__ dL_dopa,
                                                              float* __restrict__ dL_dmeans,
@@ -168,10 +184,20 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_unpack_grads(int64_t n, const fl
     const float4* row = reinterpret_cast<const float4*>(acc + i * CUGS_GRAD_STRIDE);
     const float4 r0 = row[0], r1 = row[1];
     const float r2 = acc[i * CUGS_GRAD_STRIDE + 8];
+    float a, b, c;
+    if (PACKED) {
+        const float4* rec = reinterpret_cast<const float4*>(packed + i * CUGS_PACKED_STRIDE);
+        const float4 p0 = rec[0];
+        a = p0.z; b = p0.w; c = rec[1].x;
+    } else {
+        a = cov_2d_inv[i * 3 + 0]; b = cov_2d_inv[i * 3 + 1]; c = cov_2d_inv[i * 3 + 2];
+    }
     dL_drgb[i * 3 + 0] = r0.x; dL_drgb[i * 3 + 1] = r0.y; dL_drgb[i * 3 + 2] = r0.z;
     dL_dopa[i] = r0.w;
-    dL_dmeans[i * 2 + 0] = r1.x; dL_dmeans[i * 2 + 1] = r1.y;
-    dL_dcov[i * 3 + 0] = r1.z; dL_dcov[i * 3 + 1] = r1.w; dL_dcov[i * 3 + 2] = r2;
+    const GradMoments m{r1.x, r1.y, r1.z, r1.w, r2};
+    const Grad2D g = grads_from_moments(m, a, b, c);
+    dL_dmeans[i * 2 + 0] = g.mx; dL_dmeans[i * 2 + 1] = g.my;
+    dL_dcov[i * 3 + 0] = g.a; dL_dcov[i * 3 + 1] = g.b; dL_dcov[i * 3 + 2] = g.c;
 }
 
 }  // namespace
@@ -191,54 +217,83 @@ extern "C" int cugs_rasterize_backward(int width, int height, const float backgr
     const int n_soa = (dL_drgb != nullptr) + (dL_dopacity_act != nullptr) + (dL_dmeans_2d != nullptr) +
                       (dL_dcov_2d_inv != nullptr);
     if (n_soa != 0 && n_soa != 4) return CUGS_EINVAL;
+    if (n_soa == 4 && !packed && !cov_2d_inv) return CUGS_EINVAL;
+    if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    CUGS_RETURN_IF_HIP(hipMemsetAsync(grad_accum, 0, sizeof(float) * CUGS_GRAD_STRIDE * (size_t)n, st));
+    int64_t rows = n;
+#ifdef CUGS_DEV
+    const bool stats = cugs_dev_backward_stats();          // the caller allocated n + 1 rows (tools/ablate_backward.py)
+    if (stats) rows = n + 1;
+#endif
+    CUGS_RETURN_IF_HIP(hipMemsetAsync(grad_accum, 0, sizeof(float) * CUGS_GRAD_STRIDE * (size_t)rows, st));
 
     const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
     if (ntx > 0 && nty > 0 && gaussian_indices) {               // backward.cu:267-269; NULL indices = no pairs
         if (!tile_ranges || !dL_dcolor || !final_T || !n_contrib) return CUGS_EINVAL;
         if (!packed && (!means_2d || !cov_2d_inv || !rgb || !opacities_act)) return CUGS_EINVAL;
-        if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
         if ((int64_t)width * height > 2147483647ll / 3) return CUGS_EOVERFLOW;
         RasterGeom geo{width, height, ntx, ntx * nty, background_host[0], background_host[1], background_host[2]};
         RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act};
-        const char* abl_env = getenv("CUGS_BWD_ABLATE");          // timing experiments only
-        const int abl = abl_env ? atoi(abl_env) : 0;
-#define CUGS_LAUNCH_BWD(P, A)                                                                              \
-    hipLaunchKernelGGL((k_raster_backward<P, A>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src, \
+        const bool wide = rows > (int64_t(1) << 26);            // 64-byte rows beyond a 32-bit byte offset
+#define CUGS_LAUNCH_BWD(P, W, S)                                                                              \
+    hipLaunchKernelGGL((k_raster_backward<P, W, S>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src, \
                        dL_dcolor, final_T, n_contrib, grad_accum, n)
+#ifdef CUGS_DEV
+        if (stats) {
+            if (packed) CUGS_LAUNCH_BWD(true, true, true); else CUGS_LAUNCH_BWD(false, true, true);
+        } else
+#endif
         if (packed) {
-            if (abl == 1) CUGS_LAUNCH_BWD(true, 1);
-            else if (abl == 2) CUGS_LAUNCH_BWD(true, 2);
-            else if (abl == 3) CUGS_LAUNCH_BWD(true, 3);
-            else if (abl == 4) CUGS_LAUNCH_BWD(true, 4);
-            else CUGS_LAUNCH_BWD(true, 0);
+            if (wide) CUGS_LAUNCH_BWD(true, true, false); else CUGS_LAUNCH_BWD(true, false, false);
         } else {
-            CUGS_LAUNCH_BWD(false, 0);
+            if (wide) CUGS_LAUNCH_BWD(false, true, false); else CUGS_LAUNCH_BWD(false, false, false);
         }
 #undef CUGS_LAUNCH_BWD
         CUGS_LAUNCH_CHECK();
     }
     if (n_soa == 4) {
-        hipLaunchKernelGGL(k_unpack_grads, dim3((unsigned)((n + CUGS_BLOCK - 1) / CUGS_BLOCK)), dim3(CUGS_BLOCK),
-                           0, st, n, grad_accum, dL_drgb, dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv);
+        const dim3 grid((unsigned)((n + CUGS_BLOCK - 1) / CUGS_BLOCK));
+        if (packed)
+            hipLaunchKernelGGL(k_unpack_grads<true>, grid, dim3(CUGS_BLOCK), 0, st, n, grad_accum, packed, cov_2d_inv,
+                               dL_drgb, dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv);
+        else
+            hipLaunchKernelGGL(k_unpack_grads<false>, grid, dim3(CUGS_BLOCK), 0, st, n, grad_accum, packed, cov_2d_inv,
+                               dL_drgb, dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv);
         CUGS_LAUNCH_CHECK();
     }
     return 0;
 }
 
-// ---- test hook (not part of include/cugs_hip.h): one wave runs reduce9 on caller data ----------
-// in: [9][64] floats (value k of lane l at k*64+l); out: [64] floats (each lane's result), slots: [64] ints.
+#ifdef CUGS_DEV
+// ---- development hooks (libcugs_hip_dev.so only; not part of include/cugs_hip.h) ------------------
+// cugsdbg_reduce9: one wave runs reduce9t on caller data.  in: [9][64] floats (value k of lane l at k*64+l,
+// k = slot); out: [64] floats (each lane's result), slots: [64] ints.
+// cugsdbg_rcp: out[i] = v_rcp_f32(in[i]).
 namespace {
 __global__ void k_dbg_reduce9(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ slots) {
     const int l = threadIdx.x;
-    out[l] = reduce9(in[0 * 64 + l], in[1 * 64 + l], in[2 * 64 + l], in[3 * 64 + l], in[4 * 64 + l], in[5 * 64 + l],
-                     in[6 * 64 + l], in[7 * 64 + l], in[8 * 64 + l], l);
-    slots[l] = reduce9_slot(l);
+    const bool side = (l & 8) != 0;
+    const float v0 = in[0 * 64 + l], v1 = in[1 * 64 + l];
+    out[l] = reduce9t(side ? v1 : v0, side ? v0 : v1, in[2 * 64 + l], in[3 * 64 + l], in[4 * 64 + l], in[5 * 64 + l],
+                      in[6 * 64 + l], in[8 * 64 + l], in[7 * 64 + l]);
+    slots[l] = reduce9t_slot(l);
 }
+__global__ void k_dbg_rcp(const float* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __builtin_amdgcn_rcpf(in[i]);
+}
+bool g_dev_backward_stats = false;
 }  // namespace
+bool cugs_dev_backward_stats() { return g_dev_backward_stats; }
+extern "C" int cugsdbg_backward_stats(int on) { g_dev_backward_stats = (on != 0); return 0; }
 extern "C" int cugsdbg_reduce9(const float* in, float* out, int* slots, void* stream) {
     hipLaunchKernelGGL(k_dbg_reduce9, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in, out, slots);
     CUGS_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int cugsdbg_rcp(const float* in, float* out, int n, void* stream) {
+    hipLaunchKernelGGL(k_dbg_rcp, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, n);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
+#endif

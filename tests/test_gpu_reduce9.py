@@ -1,7 +1,9 @@
-"""reduce9 (cugs_raster_common.h): the 9-value wave64 transpose-reduce built on gfx950's
-v_permlane32_swap / v_permlane16_swap + DPP.  Exercised alone through the library's test hook
-(cugsdbg_reduce9, not part of the public C ABI) with exact integer-valued data."""
+"""reduce9t (cugs_raster_common.h): the 9-value wave64 transpose-reduce built on bank-masked DPP adds and
+gfx950's v_permlane16_swap / v_permlane32_swap.  Exercised alone through the DEVELOPMENT build's test hook
+(libcugs_hip_dev.so: cugsdbg_reduce9, not part of the public C ABI) with exact integer-valued data; and
+v_rcp_f32(1.0f) == 1.0f, which the blend backward relies on for pixels a Gaussian does not touch."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -10,13 +12,24 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _dev_lib(pkg):
+    path = os.path.join(os.path.dirname(pkg.LIB_PATH), "libcugs_hip_dev.so")
+    if not os.path.exists(path):
+        pytest.skip("development library not built (make -C cuda-gaussian-splatting_amd/csrc)")
+    return C.CDLL(path)
+
+
 def test_reduce9_totals_land_in_their_lanes(pkg, dev):
-    lib = C.CDLL(pkg.LIB_PATH)
+    lib = _dev_lib(pkg)
     rng = np.random.default_rng(0)
-    for trial in range(4):
+    for trial in range(6):
         vals = rng.integers(-500, 500, size=(9, 64)).astype(np.float32)     # exact in fp32
         if trial == 0:
             vals = np.array([[1000.0 * (k + 1) + l for l in range(64)] for k in range(9)], np.float32)
+        if trial == 1:                                                      # one hot lane per slot: catches lane mix-ups
+            vals = np.zeros((9, 64), np.float32)
+            for k in range(9):
+                vals[k, (7 * k + 3) % 64] = float(k + 1)
         inp = torch.from_numpy(vals).to(dev)
         out = torch.zeros(64, device=dev)
         slots = torch.zeros(64, dtype=torch.int32, device=dev)
@@ -30,3 +43,15 @@ def test_reduce9_totals_land_in_their_lanes(pkg, dev):
         for lane in range(64):
             if s[lane] >= 0:
                 assert o[lane] == want[s[lane]], (trial, lane, s[lane])
+
+
+def test_rcp_of_one_is_exactly_one(pkg, dev):
+    lib = _dev_lib(pkg)
+    x = torch.tensor([1.0, 0.5, 2.0, 0.25, 0.01, 0.99, 1e-5], dtype=torch.float32, device=dev)
+    out = torch.zeros_like(x)
+    rc = lib.cugsdbg_rcp(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int(x.numel()), C.c_void_p(0))
+    assert rc == 0
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert o[0] == 1.0 and o[1] == 2.0 and o[2] == 0.5 and o[3] == 4.0      # powers of two are exact
+    assert np.allclose(o[4:], 1.0 / x.cpu().numpy()[4:], rtol=3e-7)          # 1 ulp elsewhere
