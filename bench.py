@@ -3,6 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W [--config config3] [--adam]
 
+With N > 1 and no external launcher (RANK unset) the script starts its N ranks itself (self_launch: N fresh child
+processes, one GPU each; the parent never touches a GPU); under `python -m torch.distributed.run ... bench.py --gpus N`
+it is one of the ranks.  `n_gpus` in the JSON line is the world size RCCL reports; --gpus != world size is an error.
+
 One "step" = one pass of the hot path over one training view per GPU:
 render() + render_backward() (+ the gradient exchange over RCCL when N > 1: --exchange compact | allreduce |
 auto, the default, which times both before the warm-up and keeps the faster; + FusedAdam.step with --adam /
@@ -245,6 +249,56 @@ def parity_probe(pkg, orc, dev):
     return res
 
 
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` without an external launcher: start N fresh child processes of this script, one
+    rank (and one GPU, via LOCAL_RANK) each, with the torch.distributed rendezvous variables set.  The parent never
+    touches a GPU (no HIP call before or after the spawn) and never re-executes itself; rank 0 inherits stdout and
+    prints the one JSON line, the other ranks' stdout is dropped, stderr is shared.  Returns the exit code: 0 only
+    if every rank exited 0; when one rank fails the others are terminated (by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on these hosts (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    code = 0
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            live.remove(pr)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                print(f"bench.py: rank {procs.index(pr)} exited with {rc}; stopping the other ranks", file=sys.stderr)
+                for other in live:
+                    other.terminate()
+        time.sleep(0.05)
+    return code
+
+
+def launcher_dry_run(args, world, rank):
+    """The N-rank plumbing without a GPU (tests/test_bench_launcher.py): rendezvous over gloo, barrier, MAX over
+    ranks of a per-rank number, one JSON line from rank 0."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": dist.get_world_size(), "max_over_ranks": float(t.item()),
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,19 +317,36 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=1 << 20,
                     help="image rows blended by the CPU baseline sample (default: the whole frame, ~10 s)")
+    ap.add_argument("--launcher-dry-run", action="store_true",
+                    help="exercise the N-rank launch + rendezvous + one-JSON-line plumbing over gloo, no GPU work")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run / self_launch
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and not launched:
+        # no external launcher: start the N ranks ourselves, BEFORE anything in this process touches a GPU
+        if not args.launcher_dry_run:
+            ge._ensure_built()                                           # make (CPU only), once, not N times
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launcher_dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if launched:
+            launcher_dry_run(args, world, rank)
+        else:
+            print(json.dumps({"dry_run": True, "n_gpus": 1}), flush=True)
+        return
     if launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        world = dist.get_world_size()                                    # what RCCL actually sees
     n_gpus = world
 
     ge._ensure_built()

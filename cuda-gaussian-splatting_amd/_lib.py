@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcugs_hip.so")
+# CUGS_HIP_LIBRARY: full path of another build of the same C ABI (the development build libcugs_hip_dev.so, a
+# maintainer's own build).  Still a HIP library or nothing.
+LIB_PATH = os.environ.get("CUGS_HIP_LIBRARY") or os.path.join(_HERE, "libcugs_hip.so")
 
 PACKED_STRIDE = 12   # CUGS_PACKED_STRIDE
 GRAD_STRIDE = 16     # CUGS_GRAD_STRIDE

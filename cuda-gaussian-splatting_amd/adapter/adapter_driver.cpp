@@ -2,6 +2,7 @@
 // tests/test_gpu_cpp_adapter.py and writes raw outputs back: render -> render_backward -> FusedAdam.step.
 //   adapter_driver <dir> <n> <C> <width> <height>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -49,6 +50,18 @@ int main(int argc, char** argv) {
         fprintf(stderr, "[driver] render done\n");
         auto grads = cugs_hip::render_backward(g, out, m, cam, st);
         fprintf(stderr, "[driver] backward done\n");
+        // the reference-glue path: RenderOutput as the reference's struct carries it (no packed records) -
+        // render_backward rebuilds them and must give the same gradients
+        {
+            cugs_hip::RenderOutput stripped = out;
+            stripped.packed = torch::Tensor();
+            auto g2 = cugs_hip::render_backward(g, stripped, m, cam, st);
+            const double scale = grads.dL_dsh_coeffs.abs().max().item<double>();
+            const double diff = (g2.dL_dsh_coeffs - grads.dL_dsh_coeffs).abs().max().item<double>();
+            const double dpos = (g2.dL_dpositions - grads.dL_dpositions).abs().max().item<double>() /
+                                std::max(grads.dL_dpositions.abs().max().item<double>(), 1e-30);
+            printf("glue_repack rel_dsh=%.3e rel_dpos=%.3e\n", diff / std::max(scale, 1e-30), dpos);
+        }
         cugs_hip::FusedAdam opt({m.positions, m.sh_coeffs, m.opacities, m.scales, m.rotations},
                                 {1.6e-4f, 2.5e-3f, 0.05f, 5e-3f, 1e-3f});
         opt.apply_gradients(grads);

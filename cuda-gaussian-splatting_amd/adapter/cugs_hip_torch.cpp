@@ -256,10 +256,8 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         return o;
     }
     const int degree = std::min(settings.active_sh_degree, max_sh_degree(model.sh_coeffs));
-    if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] render: n=%lld degree=%d\n", (long long)n, degree);
     auto proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, camera,
                                   degree, settings.scale_modifier);
-    if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] projected\n");
     // The sort runs on the pair count predicted from this device's previous frame (cugs_sort_pairs_predicted) and
     // the forward blend is queued behind it before the host looks at the true count: no idle device while the
     // host waits.  A prediction that was too small is detected afterwards and the exact path re-run.
@@ -313,7 +311,6 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         const int64_t prev = known == last_pairs.end() ? 0 : known->second;
         last_pairs[dev_index] = std::max<int64_t>(srt.total_pairs, prev - prev / 32);
     }
-    if (getenv("CUGS_ADAPTER_TRACE")) fprintf(stderr, "[adapter] sorted P=%d\n", srt.total_pairs);
     o.color = fwd.color; o.final_T = fwd.final_T; o.n_contrib = fwd.n_contrib;
     o.means_2d = proj.means_2d; o.depths = proj.depths; o.cov_2d_inv = proj.cov_2d_inv; o.radii = proj.radii;
     o.rgb = proj.rgb; o.opacities_act = proj.opacities_act;
@@ -334,9 +331,19 @@ BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutpu
         return o;
     }
     const int degree = std::min(settings.active_sh_degree, max_sh_degree(model.sh_coeffs));
+    // a RenderOutput that lost its packed records (e.g. it went through the reference's struct, which has no
+    // field for them) gets them rebuilt - one 48 B/Gaussian launch - so the packed blend kernel runs either way
+    torch::Tensor packed = ro.packed;
+    if (!packed.defined() || packed.size(0) != n) {
+        packed = torch::empty({n, CUGS_PACKED_STRIDE}, fopt(dL_dcolor));
+        auto m = ro.means_2d.contiguous(), c = ro.cov_2d_inv.contiguous(), r = ro.rgb.contiguous(),
+             op = ro.opacities_act.contiguous();
+        check(cugs_pack_projected(n, ptr<float>(m), ptr<float>(c), ptr<float>(r), ptr<float>(op), ptr<float>(packed),
+                                  stream_of(dL_dcolor)), "cugs_pack_projected");
+    }
     auto rb = rasterize_backward(dL_dcolor, ro.means_2d, ro.cov_2d_inv, ro.rgb, ro.opacities_act, ro.tile_ranges,
                                  ro.gaussian_indices, ro.final_T, ro.n_contrib, camera.width, camera.height,
-                                 settings.background, static_cast<int>(n), ro.packed, /*unpack=*/false);
+                                 settings.background, static_cast<int>(n), packed, /*unpack=*/false);
     o.dL_dmeans_2d = torch::empty({n, 2}, fopt(dL_dcolor));
     auto pb = project_backward_impl(&rb.grad_accum, &ro.rgb, &o.dL_dmeans_2d, {}, {}, {}, {}, model.positions,
                                     model.rotations, model.scales, model.opacities, model.sh_coeffs, ro.radii, camera, degree,

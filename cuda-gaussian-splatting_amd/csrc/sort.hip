@@ -535,6 +535,13 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t pairs_or_ca
     }
 }
 
+#ifdef CUGS_DEV
+// ---- development build only (libcugs_hip_dev.so): ranking by one LDS atomic-with-return per item -------------
+// Measured 7 % faster than the ballot ranking (sort 0.250 -> 0.232 ms at config 3), but it relies on an ordering
+// of same-address LDS lanes that the ISA manual does not state.  The shipped library therefore always ranks with
+// wave ballots, keeps no mode variable and reads no environment; this path, its on-device probe and the
+// cugsdbg_sort_rank_mode hook exist only for experiments (tests/test_gpu_parity.py runs both modes against the
+// oracle in a child process that loads the development library).
 // Does an LDS atomic with return serve the lanes of one wave instruction that hit the SAME address in ascending
 // lane order, and successive instructions of a wave in issue order?  Each lane checks that the value it got back
 // equals the number of earlier (round, lane) items with its digit, for random, clustered, constant, same-bank and
@@ -573,20 +580,13 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_probe_lds_order(uint32_t* __rest
     if (bad) atomicAdd(violations, bad);
 }
 
-// -1: not probed yet (ballot ranking is used), 0: ballot ranking, 1: atomic ranking.  CUGS_SORT_RANK=ballot|atomic
-// overrides the probe.
+// -1: not probed yet (ballot ranking is used), 0: ballot ranking, 1: atomic ranking.
 std::atomic<int> g_rank_mode{-1};
-int rank_mode() {
-    int m = g_rank_mode.load(std::memory_order_relaxed);
-    if (m >= 0) return m;
-    const char* e = getenv("CUGS_SORT_RANK");
-    if (e && e[0]) {
-        m = (e[0] == 'a') ? 1 : 0;
-        g_rank_mode.store(m, std::memory_order_relaxed);
-        return m;
-    }
-    return -1;
-}
+int rank_mode() { return g_rank_mode.load(std::memory_order_relaxed); }
+#else
+constexpr int rank_mode() { return 0; }            // ballot ranking: defined by the ISA, no state
+#endif
+
 
 template <typename K, bool IOTA, int NT>
 int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned long long* dev_count, int shift, int bits,
@@ -599,12 +599,14 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
     }
     hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, hist, nblk, tot);
     CUGS_LAUNCH_CHECK();
+#ifdef CUGS_DEV
     if (rank_mode() == 1) {               // digit width only matters to the ballot ranking: one instantiation
         hipLaunchKernelGGL((k_radix_scatter<K, IOTA, 8, NT, true>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count,
                            shift, (1u << bits) - 1u, hist, tot, nblk, kout, vout);
         CUGS_LAUNCH_CHECK();
         return 0;
     }
+#endif
 #define CUGS_SCATTER(NB)                                                                                          \
     hipLaunchKernelGGL((k_radix_scatter<K, IOTA, NB, NT, false>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count, \
                        shift, 0u, hist, tot, nblk, kout, vout)
@@ -724,7 +726,8 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const flo
     if (ntx > 32767 || nty > 32767) return CUGS_EOVERFLOW;          // rectangle extents travel as 16-bit halves
     int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st);
     if (rc) return rc;
-    // first blocking sort of the process: verify the LDS ordering the atomic ranking relies on (64 workgroups, once)
+#ifdef CUGS_DEV
+    // development build: first blocking sort of the process verifies the LDS ordering the atomic ranking relies on
     const bool probing = rank_mode() < 0;
     uint32_t* probe_word = reinterpret_cast<uint32_t*>(ws.total) + 8;
     uint32_t violations = 1;
@@ -734,10 +737,13 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const flo
         CUGS_LAUNCH_CHECK();
         CUGS_RETURN_IF_HIP(hipMemcpyAsync(&violations, probe_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     }
+#endif
     // straight into the caller's variable: if that is pinned host memory the copy is one DMA, no staging
     CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     CUGS_RETURN_IF_HIP(hipStreamSynchronize(st));
+#ifdef CUGS_DEV
     if (probing) g_rank_mode.store(violations == 0 ? 1 : 0, std::memory_order_relaxed);
+#endif
     if ((unsigned long long)*total_pairs_host > 2147483647ull) {   // the reference indexes pairs with int
         *total_pairs_host = 0;
         return CUGS_EOVERFLOW;
@@ -815,10 +821,11 @@ extern "C" int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const floa
                                static_cast<const unsigned long long*>(ws.total), st);
 }
 
-// Debug hook (not part of the ABI header): force (0 = ballot, 1 = atomic) or query (-2) the ranking mode of the
+#ifdef CUGS_DEV
+// Debug hook (development build only, not part of the ABI header): force (0 = ballot, 1 = atomic) or query (-2) the ranking mode of the
 // radix scatter; returns the mode in effect (-1 = not probed yet).
 extern "C" int cugsdbg_sort_rank_mode(int mode) {
     if (mode == 0 || mode == 1 || mode == -1) g_rank_mode.store(mode, std::memory_order_relaxed);
     return g_rank_mode.load(std::memory_order_relaxed);
 }
-
+#endif

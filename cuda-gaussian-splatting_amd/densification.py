@@ -4,7 +4,8 @@ DensificationController with the reference's method names and schedule.
 
 Differences from the reference, all at the boundary:
   * densify() takes the split noise as an argument ([2, N, 3] standard normal, indexed by the parent;
-    drawn from torch's device generator when omitted) instead of calling randn_like internally;
+    drawn from torch's device generator when omitted) instead of calling randn_like internally; with more
+    than one rank the argument is mandatory (parallel.densify_replicated supplies one shared draw);
   * densify(..., optimizer=FusedAdam) carries the Adam moments through the surgery (survivors keep
     theirs, new Gaussians start at zero) instead of leaving the caller to rebuild the optimizer
     (trainer.cpp:267-304); without it the behaviour is the reference's;
@@ -159,6 +160,13 @@ class DensificationController:
         stats = DensificationStats(num_before=n, num_after=n)
         if n == 0:
             return stats
+        # Replicated models (data parallelism) must split with the SAME noise on every rank: each rank's own
+        # device generator would move the children differently and the replicas would drift apart silently.
+        # parallel.densify_replicated() draws the noise once and broadcasts it.
+        import torch.distributed as dist
+        if noise is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("densify: under data parallelism pass `noise` (parallel.shared_split_noise) or call "
+                               "parallel.densify_replicated(): a per-rank random draw would make the replicas diverge")
         dev = model.positions.device
         _torch_check(model.positions.is_cuda, "densify: model must be on CUDA")
         if self.grad_accum_ is None or self.grad_accum_.shape[0] != n:

@@ -116,6 +116,31 @@ def allreduce_densify_stats(controller, group: Optional[dist.ProcessGroup] = Non
     controller.grad_accum_, controller.grad_count_ = both[0].contiguous(), both[1].contiguous()
 
 
+def shared_split_noise(n: int, device, step: int, seed: int = 0, group: Optional[dist.ProcessGroup] = None,
+                       src: int = 0) -> torch.Tensor:
+    """The [2, N, 3] standard-normal split noise of DensificationController.densify, identical on every rank:
+    drawn ONCE, on rank `src`, from a CPU generator keyed by (seed, step) and broadcast (no reliance on the ranks'
+    device generators being in the same state).  Without a process group: the same draw, locally."""
+    gen = torch.Generator(device="cpu").manual_seed((int(seed) * 1_000_003 + int(step)) & 0x7FFFFFFFFFFFFFFF)
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi or dist.get_rank(group) == src:
+        noise = torch.randn((2, int(n), 3), dtype=torch.float32, generator=gen).to(device)
+    else:
+        noise = torch.empty((2, int(n), 3), dtype=torch.float32, device=device)
+    if multi:
+        dist.broadcast(noise, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    return noise
+
+
+def densify_replicated(controller, model, step: int, optimizer=None, seed: int = 0,
+                       group: Optional[dist.ProcessGroup] = None):
+    """densify() for replicated models: the statistics are made to agree (allreduce_densify_stats), the split
+    noise is one shared draw, so every rank performs the identical surgery and the replicas stay bit-equal."""
+    allreduce_densify_stats(controller, group)
+    noise = shared_split_noise(model.num_gaussians(), model.positions.device, step, seed, group)
+    return controller.densify(model, step, noise=noise, optimizer=optimizer)
+
+
 def wait_all(works: Sequence) -> None:
     for w in works:
         w.wait()

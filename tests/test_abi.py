@@ -82,3 +82,16 @@ def test_missing_library_fails_loudly(pkg, tmp_path, monkeypatch):
     with pytest.raises(ImportError, match="no fallback"):
         spec.loader.exec_module(mod)
     sys.modules.pop("cugs_lib_copy", None)
+
+
+def test_release_library_has_no_debug_surface(pkg):
+    """the shipped library exports exactly the declared C ABI (no cugsdbg_* hooks), never reads
+    the environment (no getenv import), and so cannot be switched into a timing/ablation mode by a stray variable."""
+    import subprocess
+    if os.environ.get("CUGS_HIP_LIBRARY"):
+        pytest.skip("a non-default library is loaded")
+    exported = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = sorted(l.split()[-1] for l in exported.splitlines() if " T " in l)
+    assert funcs == _declared(), set(funcs) ^ set(_declared())
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined

@@ -42,6 +42,15 @@ def _worker(rank, world, port, q):
                        rad=ctrl.max_radii_2d_.numpy().copy())
         pkg.parallel.allreduce_densify_stats(ctrl)
         compact.update(acc_out=ctrl.grad_accum_.numpy(), cnt_out=ctrl.grad_count_.numpy(), rad_out=ctrl.max_radii_2d_.numpy())
+        # split noise: one draw, identical on every rank; densify() refuses a per-rank draw under DP
+        noise = pkg.parallel.shared_split_noise(n, torch.device("cpu"), step=700, seed=3)
+        compact.update(noise=noise.numpy().copy())
+        model = pkg.GaussianModel(mk(n, 3), mk(n, 3, c), mk(n, 1), mk(n, 4), mk(n, 3))
+        try:
+            ctrl.densify(model, 700)
+            compact.update(refused=False)
+        except RuntimeError as e:
+            compact.update(refused="replicas" in str(e))
         # numpy: pickled by value (torch tensors would travel as shared-memory handles)
         q.put((rank, {k: v.numpy() for k, v in local.items()}, {k: v.numpy() for k, v in out.items()}, views, compact))
     finally:
@@ -70,6 +79,8 @@ def test_allreduce_gradients_world2_gloo():
         assert np.array_equal(c["centres"][0], c0["centre"]) and np.array_equal(c["centres"][1], c1["centre"])
         assert np.allclose(c["sum_pos"], c0["pos"] + c1["pos"]) and np.allclose(c["sum_rot"], c0["rot"] + c1["rot"])
     assert np.array_equal(c0["sum_pos"], c1["sum_pos"])
+    assert np.array_equal(c0["noise"], c1["noise"]) and c0["noise"].shape == (2, 50, 3) and c0["noise"].std() > 0.5
+    assert c0["refused"] is True and c1["refused"] is True
     for c in (c0, c1):                                 # densification statistics agree on every replica
         assert np.allclose(c["acc_out"], c0["acc"] + c1["acc"]) and np.array_equal(c["cnt_out"], c0["cnt"] + c1["cnt"])
         assert np.array_equal(c["rad_out"], np.maximum(c0["rad"], c1["rad"]))

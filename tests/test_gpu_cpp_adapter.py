@@ -33,11 +33,15 @@ def test_cpp_adapter_matches_python_host(pkg, dev, tmp_path):
     noise = torch.randn((2, n, 3), generator=torch.Generator().manual_seed(11))
     noise.numpy().tofile(tmp_path / "split_noise.bin")
 
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUGS_ADAPTER_TRACE="1")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([DRIVER, str(tmp_path), str(n), "16", str(w), str(h)], capture_output=True, text=True,
                          timeout=300, env=env)
     assert res.returncode == 0, f"rc={res.returncode} stdout={res.stdout!r} stderr={res.stderr!r}"
     assert "torch_check=1" in res.stdout                     # TORCH_CHECK -> c10::Error on a CPU tensor
+    # reference-glue path: a RenderOutput without the packed scratch (the reference's struct has no field for it)
+    # gets the records rebuilt and runs the same packed blend kernel: same gradients up to atomic order
+    repack = [l for l in res.stdout.splitlines() if l.startswith("glue_repack ")][0].split()
+    assert float(repack[1].split("=")[1]) <= 1e-5 and float(repack[2].split("=")[1]) <= 1e-5, repack
 
     model = pkg.scene.to_model(arrays, dev)
     settings = pkg.RenderSettings(background=bg, active_sh_degree=deg)

@@ -2,7 +2,8 @@
 one GPU of the box, the compact exchange between them (all-gather of the gated colour gradients and camera
 centres + in-place all-reduce of the flat geometry gradients; gloo carries the bytes here - RCCL needs one GPU
 per rank - through the same parallel.collect_views code path), the SH rebuild on each rank.  Every rank must end
-up with the sum of the two views' gradients, bit-identical SH gradients on both ranks."""
+up with the sum of the two views' gradients, bit-identical SH gradients on both ranks; then both replicas densify
+(statistics reduced, one shared noise draw) and must stay bit-equal."""
 import os
 import sys
 
@@ -42,9 +43,29 @@ def _worker(rank, world, port, q):
         assert pending == []
         flat.copy_(flat_cpu)                                   # the summed geometry gradients back on the device
         d_sh = pkg.sh_backward_views(DEG, model.positions, views.to(dev), centres.tolist(), int(model.sh_coeffs.shape[2]))
+        # N2 under data parallelism: per-view statistics -> SUM/SUM/MAX over the ranks (host copies: gloo), ONE
+        # shared draw of the split noise, then the identical surgery on every replica
+        ctrl = pkg.DensificationController(pkg.DensificationConfig(grad_threshold=2e-8, percent_dense=0.004), 5.0)
+        ctrl.accumulate_gradients(grads.dL_dmeans_2d, out.radii)
+        host_ctrl = pkg.DensificationController(ctrl.config_, 5.0)
+        host_ctrl.grad_accum_, host_ctrl.grad_count_, host_ctrl.max_radii_2d_ = (
+            ctrl.grad_accum_.cpu(), ctrl.grad_count_.cpu(), ctrl.max_radii_2d_.cpu())
+        pkg.parallel.allreduce_densify_stats(host_ctrl)
+        ctrl.grad_accum_, ctrl.grad_count_, ctrl.max_radii_2d_ = (
+            host_ctrl.grad_accum_.to(dev), host_ctrl.grad_count_.to(dev), host_ctrl.max_radii_2d_.to(dev))
+        refused = False
+        try:
+            ctrl.densify(model, 600)                            # no noise under DP: must refuse
+        except RuntimeError:
+            refused = True
+        noise = pkg.parallel.shared_split_noise(N, torch.device("cpu"), step=600, seed=5).to(dev)
+        stats = ctrl.densify(model, 600, noise=noise)
         q.put((rank, {"sh": d_sh.cpu().numpy(), "pos": grads.dL_dpositions.cpu().numpy(),
                       "rot": grads.dL_drotations.cpu().numpy(), "scl": grads.dL_dscales.cpu().numpy(),
-                      "opa": grads.dL_dopacities.cpu().numpy(), "pairs": out.total_pairs}))
+                      "opa": grads.dL_dopacities.cpu().numpy(), "pairs": out.total_pairs, "refused": refused,
+                      "densify": (stats.num_cloned, stats.num_split, stats.num_pruned, stats.num_after),
+                      "model": {k: getattr(model, k).cpu().numpy() for k in
+                                ("positions", "sh_coeffs", "opacities", "rotations", "scales")}}))
     finally:
         dist.destroy_process_group()
 
@@ -77,3 +98,8 @@ def test_two_ranks_two_views_compact_exchange(pkg, dev):
         for rank in (0, 1):
             assert np.max(np.abs(res[rank][k].reshape(ref.shape) - ref)) / scale <= 1e-5, (k, rank)
     assert np.array_equal(res[0]["sh"], res[1]["sh"])          # rebuilt in view order: identical on every rank
+    # densification under DP: refused without shared noise; with it the replicas are bit-equal after the surgery
+    assert res[0]["refused"] and res[1]["refused"]
+    assert res[0]["densify"] == res[1]["densify"] and res[0]["densify"][1] > 0 and res[0]["densify"][0] > 0
+    for k, v in res[0]["model"].items():
+        assert v.shape[0] == res[0]["densify"][3] and np.array_equal(v, res[1]["model"][k]), k

@@ -8,6 +8,8 @@ rendered RGB and on every gradient.  Tolerances are written at each assert.
 Equality is with the CPU restatement of the reference's CUDA source (oracle/cugs_oracle.c), not
 with bits from an nvcc build.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -77,30 +79,53 @@ def test_sort_parity_bit_exact(pkg, orc, dev, n, w, h, mu_s):
     assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])                          # per-tile spans
 
 
-def test_sort_ranking_modes_agree_and_probe_selects_one(pkg, orc, dev):
-    """The radix scatter ranks either with wave ballots (match-any) or with one LDS atomic-with-return per item,
-    which relies on the LDS serving same-address lanes in lane order - verified on the device by a probe before
-    it is ever used.  Both must give the oracle's order; the probe must have settled on a mode by now."""
+_RANK_MODES_CHILD = r"""
+import ctypes as C, json, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import __graft_entry__ as ge
+from util import oracle_forward, np_
+pkg, orc = ge.load_package(), ge.load_oracle()
+from cugs_amd._lib import lib
+fn = lib.cugsdbg_sort_rank_mode
+fn.restype, fn.argtypes = C.c_int, [C.c_int]
+dev = torch.device("cuda:0")
+n, w, h = 60000, 1280, 720
+arrays = pkg.scene.make_gaussians(n, w, h, sh_degree=0, seed=8, mu_s=-4.0)
+cam = pkg.scene.make_camera(w, h)
+ref = oracle_forward(orc, arrays, cam, degree=0)
+t = lambda k: torch.from_numpy(ref[k]).to(dev)
+pkg.sort_gaussians(t("means_2d"), t("depths"), t("radii"), t("tiles_touched"), w, h)      # runs the probe
+res = {"chosen": fn(-2), "modes": {}}
+for mode in (0, 1):
+    assert fn(mode) == mode
+    srt = pkg.sort_gaussians(t("means_2d"), t("depths"), t("radii"), t("tiles_touched"), w, h)
+    res["modes"][mode] = bool(np.array_equal(np_(srt.gaussian_keys_sorted).view(np.uint64), ref["keys"])
+                              and np.array_equal(np_(srt.gaussian_values_sorted), ref["values"])
+                              and np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"]))
+print(json.dumps(res))
+"""
+
+
+def test_sort_ranking_modes_agree_in_the_development_build(pkg, dev):
+    """The shipped library ranks with wave ballots only (no mode variable, no environment, no cugsdbg_* export).
+    The development build also carries the ranking by one LDS atomic-with-return per item, which relies on an
+    undocumented ordering of same-address LDS lanes and is selected there by an on-device probe: a child process
+    that loads that build must get the oracle's order in both modes."""
     import ctypes as C
-    from cugs_amd._lib import lib
-    fn = lib.cugsdbg_sort_rank_mode
-    fn.restype, fn.argtypes = C.c_int, [C.c_int]
-    n, w, h = 60000, 1280, 720
-    arrays, cam = _scene(pkg, n, w, h, 0, seed=8, mu_s=-4.0)
-    ref = oracle_forward(orc, arrays, cam, degree=0)
-    t = lambda k: torch.from_numpy(ref[k]).to(dev)
-    pkg.sort_gaussians(t("means_2d"), t("depths"), t("radii"), t("tiles_touched"), w, h)     # triggers the probe if needed
-    chosen = fn(-2)
-    assert chosen in (0, 1)
-    try:
-        for mode in (0, 1):
-            assert fn(mode) == mode
-            srt = pkg.sort_gaussians(t("means_2d"), t("depths"), t("radii"), t("tiles_touched"), w, h)
-            assert np.array_equal(np_(srt.gaussian_keys_sorted).view(np.uint64), ref["keys"]), mode
-            assert np.array_equal(np_(srt.gaussian_values_sorted), ref["values"]), mode
-            assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"]), mode
-    finally:
-        fn(chosen)
+    import json
+    import subprocess
+    import sys
+    assert not hasattr(C.CDLL(pkg.LIB_PATH), "cugsdbg_sort_rank_mode")
+    dev_lib = os.path.join(os.path.dirname(pkg.LIB_PATH), "libcugs_hip_dev.so")
+    if not os.path.exists(dev_lib):
+        pytest.skip("development library not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _RANK_MODES_CHILD, root], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, CUGS_HIP_LIBRARY=dev_lib))
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["chosen"] in (0, 1) and out["modes"] == {"0": True, "1": True}
 
 
 def test_sort_predicted_capacity_path(pkg, orc, dev):

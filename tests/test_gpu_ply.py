@@ -94,3 +94,27 @@ def test_name_based_loading_and_errors(pkg, po, dev, tmp_path):
     # the writer returns False, like the reference, for an invalid model or an unwritable path
     assert not pkg.write_gaussian_ply(tmp_path / "x.ply", pkg.GaussianModel())
     assert not pkg.write_gaussian_ply(tmp_path / "no_such_dir" / "x.ply", _to_model(pkg, ref, dev))
+
+
+@pytest.mark.parametrize("n,degree", [(50, 3), (20, 0), (30, 2)])
+def test_reference_roundtrip_degrees_on_the_product(pkg, dev, tmp_path, n, degree):
+    """tests/test_gaussian_model.cpp:97-141 (RoundtripDegree3 / 0 / 2) through the HIP record pack/unpack."""
+    ref = make_model(n, (degree + 1) ** 2, seed=100 + degree)
+    original = _to_model(pkg, ref, dev)
+    path = tmp_path / ("test_d%d.ply" % degree)
+    assert original.save_ply(path) if hasattr(original, "save_ply") else pkg.write_gaussian_ply(path, original)
+    assert path.exists()
+    loaded = pkg.read_gaussian_ply(path)
+    assert loaded.is_valid() and loaded.num_gaussians() == n and loaded.max_sh_degree() == degree
+    for k in NAMES:
+        assert torch.allclose(getattr(original, k).cpu(), getattr(loaded, k), rtol=1e-5, atol=1e-5), k
+
+
+def test_reference_empty_model_on_the_product(pkg, dev, tmp_path):
+    """tests/test_gaussian_model.cpp:143-157 (EmptyModel): an empty model saves and loads back empty."""
+    m = pkg.GaussianModel(torch.zeros((0, 3), device=dev), torch.zeros((0, 3, 16), device=dev),
+                          torch.zeros((0, 1), device=dev), torch.zeros((0, 4), device=dev), torch.zeros((0, 3), device=dev))
+    path = tmp_path / "empty.ply"
+    assert pkg.write_gaussian_ply(path, m)
+    loaded = pkg.read_gaussian_ply(path)
+    assert loaded.num_gaussians() == 0

@@ -1,7 +1,8 @@
 """SURVEY §8(f) N3 — the PLY checkpoint oracle (oracle/ply_oracle.py) against the byte layout the reference's
 source states (utils/ply_io.cpp:123-190: header text, per-vertex float order, (coefficient, channel) interleave of
-f_rest) and its reader's rules (:211-351).  The reference's own tests do not cover this writer: parity unpinned
-beyond this."""
+f_rest) and its reader's rules (:211-351), and pinned by the reference's own Gaussian-PLY tests
+(tests/test_gaussian_model.cpp:97-160: RoundtripDegree3 / Degree0 / Degree2, EmptyModel), restated below with the
+reference's model sizes and its allclose(1e-5, 1e-5) bar (the round trips here are in fact exact)."""
 import importlib.util
 import os
 import struct
@@ -102,3 +103,31 @@ def test_state_extension_round_trip_and_stays_loadable_without_it(po, tmp_path):
     head = path.read_bytes().partition(b"end_header\n")[0].decode().split("\n")
     assert head[2] == "comment cugs_adam_step 1234" and head[3] == "element vertex 20"
     assert len([l for l in head if l.startswith("property")]) == (14 + 12) + 2 * (11 + 12)
+
+
+# ---- the reference's own tests: tests/test_gaussian_model.cpp:97-160 (GaussianPlyTest) ---------------------
+def _max_sh_degree(sh):                                   # GaussianModel::max_sh_degree (gaussian.hpp)
+    return int(round(np.sqrt(sh.shape[2]))) - 1
+
+
+@pytest.mark.parametrize("n,degree", [(50, 3), (20, 0), (30, 2)])    # RoundtripDegree3, RoundtripDegree0, RoundtripDegree2
+def test_reference_roundtrip_degrees(po, tmp_path, n, degree):
+    original = make_model(n, (degree + 1) ** 2, seed=100 + degree)   # make_test_model(n, degree): randn tensors
+    path = tmp_path / ("test_d%d.ply" % degree)
+    assert po.write_gaussian_ply(path, original) and path.exists()   # ASSERT_TRUE(save_ply), exists
+    loaded, _ = po.read_gaussian_ply(path)
+    assert loaded["positions"].shape == (n, 3) and _max_sh_degree(loaded["sh_coeffs"]) == degree
+    assert loaded["sh_coeffs"].shape == (n, 3, (degree + 1) ** 2) and loaded["opacities"].shape == (n, 1)
+    for k in original:                                               # EXPECT_TRUE(allclose(..., 1e-5, 1e-5))
+        assert np.allclose(original[k], loaded[k], rtol=1e-5, atol=1e-5), k
+        assert np.array_equal(original[k], loaded[k]), k             # and in fact exact
+
+
+def test_reference_empty_model(po, tmp_path):                        # GaussianPlyTest.EmptyModel
+    empty = dict(positions=np.zeros((0, 3), np.float32), sh_coeffs=np.zeros((0, 3, 16), np.float32),
+                 opacities=np.zeros((0, 1), np.float32), rotations=np.zeros((0, 4), np.float32),
+                 scales=np.zeros((0, 3), np.float32))
+    path = tmp_path / "empty.ply"
+    assert po.write_gaussian_ply(path, empty)
+    loaded, _ = po.read_gaussian_ply(path)
+    assert loaded["positions"].shape[0] == 0
