@@ -248,3 +248,56 @@ __device__ __forceinline__ float reduce9t(float cA, float cB, float v2, float v3
         : "v"(cA), "v"(cB), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v8), "v"(v7));
     return d;
 }
+
+// ---------------------------------------------------------------------------------------
+// reduce9r16: the same transpose-reduce inside each 16-lane DPP ROW independently (four rows = four different
+// Gaussians in the blend backward's second phase).  Stages 1 and 2 as in reduce9t (bank-masked DPP, first pair
+// swizzled by lane bit 3); the two in-bank stages use selects (side = lane bit 1, then bit 0): there is no mask
+// finer than a bank.  9 -> 5 -> 3 -> 2 -> 1 values; ~36 units per call = 9 per row.
+// Result, per row: lane r (0..15) returns the ROW total of slot reduce9r16_slot(r):
+//   r = 4*bank + 0 -> slots 0, 2, 1, 3 (bank 0..3);  r = 4*bank + 2 -> slots 4, 6, 5, 8;  r = 1 -> slot 7.
+// ---------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float xchg_add(bool side, float a, float b) {
+    return (side ? b : a) + dpp_mov<CTRL>(side ? a : b);
+}
+
+__device__ __forceinline__ int reduce9r16_slot(int lane) {
+    const int r = lane & 15, bank = r >> 2;
+    const int perm[4] = {0, 2, 1, 3};
+    if ((r & 3) == 0) return perm[bank];
+    if ((r & 3) == 2) return bank == 3 ? 8 : 4 + perm[bank];
+    if (r == 1) return 7;
+    return -1;
+}
+
+__device__ __forceinline__ float reduce9r16(float cA, float cB, float v2, float v3, float v4, float v5, float v6,
+                                            float v8, float v7, int lane) {
+    float a0, a1, a2, a3, a4, b0, b1, b2;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %9, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"        // a0 = cA + mirror(cB)
+        "v_add_f32_dpp %1, %10, %10 row_mirror row_mask:0xf bank_mask:0x3\n\t"      // a1 = v2 | v3
+        "v_add_f32_dpp %1, %11, %11 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0x3\n\t"      // a2 = v4 | v5
+        "v_add_f32_dpp %2, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %14, %14 row_mirror row_mask:0xf bank_mask:0x3\n\t"      // a3 = v6 | v8
+        "v_add_f32_dpp %3, %15, %15 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %16, %16 row_mirror row_mask:0xf bank_mask:0xf\n\t"      // a4 = v7
+        "v_add_f32_dpp %5, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   // b0 = a0 | a1
+        "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"   // b2 = a4
+        "v_add_f32_dpp %6, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   // b1 = a2 | a3
+        "v_add_f32_dpp %6, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1\n\t"                                                               // the compiler's DPP reads b1 next
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(b0), "=&v"(b1), "=&v"(b2)
+        : "v"(cA), "v"(cB), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v8), "v"(v7));
+    const bool s1 = (lane & 2) != 0, s0 = (lane & 1) != 0;
+    const float c0 = xchg_add<0x4E>(s1, b0, b1);                   // quad_perm [2,3,0,1]
+    const float c1 = b2 + dpp_mov<0x4E>(b2);
+    return xchg_add<0xB1>(s0, c0, c1);                             // quad_perm [1,0,3,2]
+}

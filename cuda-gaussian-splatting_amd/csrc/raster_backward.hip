@@ -10,10 +10,10 @@
 //
 // What is different from the reference is the scatter.  The reference issues nine float atomics
 // per (pixel, Gaussian) contribution (backward.cu:217-228).  Here all 64 pixels of a wave look at
-// the same Gaussian in the same step, so the nine partials are first summed across the wave
-// (reduce9t, cugs_raster_common.h) and then leave the wave as ONE atomic wave-instruction whose nine
-// active lanes hit nine consecutive floats of the Gaussian's 64-byte-aligned accumulator row - a
-// single memory-side request (MI355X_MICROARCH.md, Global float atomics).
+// the same Gaussian in the same step, so the partials are summed across the wave first (through LDS and a
+// 16-lane DPP reduction, see the kernel's comment) and leave it as ONE atomic wave-instruction per four
+// Gaussians, nine active lanes per Gaussian hitting nine consecutive floats of its 64-byte-aligned
+// accumulator row - a single memory-side request each (MI355X_MICROARCH.md, Global float atomics).
 //
 // The kernel is bound by VALU issue (profiles/README.md), so the step is written for instruction
 // count, priced with the measured costs in cugs_raster_common.h:
@@ -39,6 +39,21 @@ bool cugs_dev_backward_stats();
 
 namespace {
 
+// Two phases per wave:
+//   phase 1, once per (wave, Gaussian) step, lane = pixel of the wave's 8x8 quad: the decisions, the T and D
+//     recurrences and the two per-pixel scalars every gradient of this contribution is made of -
+//     weight = alpha T (for dL/dcolour) and v3 = gated dL/dalpha * e (dL/dopacity; dL/dpower = v3 * opacity) -
+//     written to LDS as one 8-byte store per lane;
+//   phase 2, once per CUGS_BWD_HITS steps, lane = (Gaussian h = lane / 16, pixel group g = lane % 16 of four
+//     horizontally adjacent pixels): reads its Gaussian's contributions back, forms the nine sums over its four
+//     pixels (the per-lane constants are the pixels' dL/dcolour and coordinates; dy is common to the four, so
+//     sum dpw dy, dx dy, dy^2 follow from the others), reduces them across the 16 lanes of its DPP row
+//     (reduce9r16) and issues one atomic instruction: nine lanes per Gaussian, one 64-byte request each.
+// Against reducing nine values over 64 lanes in every step (38 units) this costs ~19 units per step; the pending
+// Gaussians are flushed before the record batch they point into is re-staged.
+#define CUGS_BWD_HITS 4
+#define CUGS_BWD_HSTRIDE 66        /* float2 per Gaussian block: 64 pixels + 16 bytes (bank spread of the b128 reads) */
+
 // WIDE: accumulator larger than 4 GiB (n > 2^26 rows): 64-bit scatter addresses.
 // STATS (dev builds only): step counters written to accumulator row `stats_row` (tools/ablate_backward.py).
 template <bool PACKED, bool WIDE, bool STATS>
@@ -48,6 +63,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                                                                 const int32_t* __restrict__ n_contrib,
                                                                 float* __restrict__ grad_accum, int64_t stats_row) {
     __shared__ float4 s_rec[CUGS_BLOCK * CUGS_REC_F4];
+    __shared__ float2 s_contrib[4][CUGS_BWD_HITS][CUGS_BWD_HSTRIDE];
+    __shared__ int s_hitrec[4][CUGS_BWD_HITS];
     __shared__ int s_wave_done[4];
 
     const unsigned tile = cugs_xcd_remap(blockIdx.x, (unsigned)geo.ntiles);
@@ -73,9 +90,26 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         dC1 = dL_dcolor[pix * 3 + 1];
         dC2 = dL_dcolor[pix * 3 + 2];
     }
-    // reduce9t's first pair arrives swizzled: red's product in side-0 lanes (lane bit 3 clear), green's in side-1
+    // ---- phase-2 constants: this lane's Gaussian slot h and its four pixels (row gy, columns gx0 .. gx0+3)
+    const int h2 = lane >> 4, g2i = lane & 15;
+    const int gx0 = quad_x + (g2i & 1) * 4, gy = quad_y + (g2i >> 1);
+    const float px2 = (float)gx0 + 0.5f, py2 = (float)gy + 0.5f;
+    // reduce9r16 takes its first pair swizzled: red in lanes with bit 3 clear, green in the others
     const bool side = (lane & 8) != 0;
-    const float dCA = side ? dC1 : dC0, dCB = side ? dC0 : dC1;
+    float eA[4], eB[4], e2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float r = 0.0f, gg = 0.0f, bb = 0.0f;
+        if (gx0 + i < geo.width && gy < geo.height) {
+            const int q = (gy * geo.width + gx0 + i) * 3;
+            r = dL_dcolor[q + 0]; gg = dL_dcolor[q + 1]; bb = dL_dcolor[q + 2];
+        }
+        eA[i] = side ? gg : r; eB[i] = side ? r : gg; e2[i] = bb;
+    }
+    const int slot2 = reduce9r16_slot(lane);
+    const unsigned slot_off = (unsigned)(slot2 < 0 ? 0 : slot2) * 4u;
+    if (lane < CUGS_BWD_HITS) s_hitrec[wave][lane] = 0;       // stale slots of a partial flush must stay valid indices
+
     // D = sum_c dL/dC_c * (colour accumulated behind the current Gaussian), starting from the background
     float D = fmaf(dC2, T * geo.bg2, fmaf(dC1, T * geo.bg1, dC0 * (T * geo.bg0)));      // backward.cu:83-87
     // rem = n_contrib - (passing Gaussians seen so far, counted from the END: Q1).  A pixel stops - without
@@ -84,9 +118,42 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     float rem = (inside && max_contrib > 0) ? (float)max_contrib : -1.0f;
     float open = (inside && max_contrib > 0) ? 1.0f : 0.0f;
     bool wave_done = (__ballot(open != 0.0f) == 0ull);
-    const int my_slot = reduce9t_slot(lane);
-    const unsigned slot_off = (unsigned)(my_slot < 0 ? 0 : my_slot) * 4u;
+    int pending = 0;                                            // Gaussians waiting in s_contrib (wave-uniform)
     unsigned st_steps = 0, st_contrib = 0, st_lanes = 0, st_batches = 0, st_tested = 0, st_open = 0;   // STATS only
+
+    // phase 2 for the `cnt` pending Gaussians of this wave
+    auto flush = [&](int cnt) {
+        const int rec = s_hitrec[wave][h2];                                            // float4 index of the record
+        const float4* c4 = reinterpret_cast<const float4*>(&s_contrib[wave][h2][g2i * 4]);
+        const float4 p01 = c4[0], p23 = c4[1];                                         // (weight, v3) x 4 pixels
+        const float2 mean = *reinterpret_cast<const float2*>(&s_rec[rec]);
+        const float4 tail = s_rec[rec + 2];                                            // opacity, tau, index, 1/c
+        const float dy = py2 - mean.y;
+        const float dx0 = px2 - mean.x, dx1 = dx0 + 1.0f, dx2 = dx0 + 2.0f, dx3 = dx0 + 3.0f;
+        float t = p01.y * dx0;
+        float A = p01.y, M1 = t, Mxx = t * dx0;
+        float RA = p01.x * eA[0], RB = p01.x * eB[0], R2 = p01.x * e2[0];
+        t = p01.w * dx1; A += p01.w; M1 += t; Mxx = fmaf(t, dx1, Mxx);
+        RA = fmaf(p01.z, eA[1], RA); RB = fmaf(p01.z, eB[1], RB); R2 = fmaf(p01.z, e2[1], R2);
+        t = p23.y * dx2; A += p23.y; M1 += t; Mxx = fmaf(t, dx2, Mxx);
+        RA = fmaf(p23.x, eA[2], RA); RB = fmaf(p23.x, eB[2], RB); R2 = fmaf(p23.x, e2[2], R2);
+        t = p23.w * dx3; A += p23.w; M1 += t; Mxx = fmaf(t, dx3, Mxx);
+        RA = fmaf(p23.z, eA[3], RA); RB = fmaf(p23.z, eB[3], RB); R2 = fmaf(p23.z, e2[3], R2);
+        // dL/dpower = v3 * opacity (alpha = opacity * e where the gate is open); dy is common to the four pixels
+        const float oA = tail.x * A;
+        M1 *= tail.x; Mxx *= tail.x;
+        const float M1y = dy * oA, Myy = dy * M1y, Mxy = dy * M1;
+        const float total = reduce9r16(RA, RB, R2, A, M1, M1y, Mxx, Myy, Mxy, lane);
+        if (slot2 >= 0 && h2 < cnt) {
+            const int g = __float_as_int(tail.z);
+            if (WIDE) {
+                atomicAdd(grad_accum + (int64_t)g * CUGS_GRAD_STRIDE + slot2, total);
+            } else {
+                const unsigned off = ((unsigned)g << 6) + slot_off;               // row bytes = 4 * CUGS_GRAD_STRIDE = 64
+                atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(grad_accum) + off), total);
+            }
+        }
+    };
 
     for (int batch = num_batches - 1; batch >= 0; --batch) {
         if (lane == 0) s_wave_done[wave] = wave_done ? 1 : 0;
@@ -113,12 +180,13 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                     if (STATS) ++st_steps;
                     const int bit = 63 - __builtin_clzll(mask);
                     mask &= ~(1ull << bit);
-                    const float4* rp = s_rec + (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
-                    const float4 g0 = rp[0], g1 = rp[1], g2 = rp[2];
+                    const int rec = (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
+                    const float4 g0 = s_rec[rec], g1 = s_rec[rec + 1];
+                    const float o = s_rec[rec + 2].x;
 
                     // ---- decisions (backward.cu:123-145) as 0/1 floats
                     PixelEval e;
-                    const float alpha = pixel_alpha_raw(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g2.x, open, e);
+                    const float alpha = pixel_alpha_raw(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, o, open, e);
                     const float passf = passes_alpha_min(alpha);           // alpha >= 1/255 (0 for a finished pixel)
                     rem -= passf;                                          // contributors counted from the END (Q1)
                     open = sat_add(rem, 1.0f);                             // 0 once a passer fell beyond n_contrib
@@ -128,35 +196,29 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                     // dL/drgb still flows
                     const float gk = k * below_alpha_cap(alpha);
 
-                    // ---- values (v_rcp_f32 + FMAs); k == 0 makes every sum below exactly zero
+                    // ---- values (v_rcp_f32 + FMAs); k == 0 makes both outputs exactly zero
                     const float rcp = __builtin_amdgcn_rcpf(1.0f - al);    // al <= 0.99; rcp(1) == 1 exactly
                     T *= rcp;                                              // T_before = T_after / (1 - alpha)
                     const float weight = al * T;
                     const float G = fmaf(dC2, g1.w, fmaf(dC1, g1.z, dC0 * g1.y));
                     const float gate = fmaf(T, G, -(rcp * D)) * gk;        // dL/dalpha, gated
                     D = fmaf(weight, G, D);
-                    const float v3 = gate * e.e;                           // dL/dopacity_act
-                    const float dpw = gate * alpha;                        // dL/dpower
-                    const float t1 = dpw * e.dx, t2 = dpw * e.dy;          // first moments
-                    const float mxx = t1 * e.dx, mxy = t1 * e.dy, myy = t2 * e.dy;
                     if (STATS) {
                         const unsigned long long lm = __ballot(k != 0.0f);
                         if (lm) { ++st_contrib; st_lanes += __popcll(lm); st_open += __popcll(__ballot(open != 0.0f)); }
                     }
-                    // Every step reduces and adds (93% of steps contribute; an all-zero add is harmless and
-                    // cheaper than the scalar test-and-branch that would skip it).
-                    const float total = reduce9t(dCA * weight, dCB * weight, dC2 * weight, v3, t1, t2, mxx, myy, mxy);
-                    if (my_slot >= 0) {
-                        const int g = __float_as_int(g2.z);
-                        if (WIDE) {
-                            atomicAdd(grad_accum + (int64_t)g * CUGS_GRAD_STRIDE + my_slot, total);
-                        } else {
-                            const unsigned off = ((unsigned)g << 6) + slot_off;     // row bytes = 4 * CUGS_GRAD_STRIDE = 64
-                            atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(grad_accum) + off), total);
-                        }
+                    s_contrib[wave][pending][lane] = make_float2(weight, gate * e.e);
+                    if (lane == 0) s_hitrec[wave][pending] = rec;
+                    if (++pending == CUGS_BWD_HITS) {
+                        flush(CUGS_BWD_HITS);
+                        pending = 0;
                     }
                     if (__ballot(open != 0.0f) == 0ull) { wave_done = true; break; }
                 }
+            }
+            if (pending) {                 // before s_rec is re-staged (and at the end of the wave's walk)
+                flush(pending);
+                pending = 0;
             }
         }
         // the next iteration's first barrier orders this batch's LDS reads before the re-staging
@@ -278,6 +340,15 @@ __global__ void k_dbg_reduce9(const float* __restrict__ in, float* __restrict__ 
                       in[6 * 64 + l], in[8 * 64 + l], in[7 * 64 + l]);
     slots[l] = reduce9t_slot(l);
 }
+// four independent rows: in [9][64], out [64] (each lane's row total), slots [64]
+__global__ void k_dbg_reduce9r16(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ slots) {
+    const int l = threadIdx.x;
+    const bool side = (l & 8) != 0;
+    const float v0 = in[0 * 64 + l], v1 = in[1 * 64 + l];
+    out[l] = reduce9r16(side ? v1 : v0, side ? v0 : v1, in[2 * 64 + l], in[3 * 64 + l], in[4 * 64 + l], in[5 * 64 + l],
+                        in[6 * 64 + l], in[8 * 64 + l], in[7 * 64 + l], l);
+    slots[l] = reduce9r16_slot(l);
+}
 __global__ void k_dbg_rcp(const float* __restrict__ in, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = __builtin_amdgcn_rcpf(in[i]);
@@ -288,6 +359,11 @@ bool cugs_dev_backward_stats() { return g_dev_backward_stats; }
 extern "C" int cugsdbg_backward_stats(int on) { g_dev_backward_stats = (on != 0); return 0; }
 extern "C" int cugsdbg_reduce9(const float* in, float* out, int* slots, void* stream) {
     hipLaunchKernelGGL(k_dbg_reduce9, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in, out, slots);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cugsdbg_reduce9r16(const float* in, float* out, int* slots, void* stream) {
+    hipLaunchKernelGGL(k_dbg_reduce9r16, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in, out, slots);
     CUGS_LAUNCH_CHECK();
     return 0;
 }

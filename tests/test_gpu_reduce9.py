@@ -45,6 +45,33 @@ def test_reduce9_totals_land_in_their_lanes(pkg, dev):
                 assert o[lane] == want[s[lane]], (trial, lane, s[lane])
 
 
+def test_reduce9r16_rows_are_independent(pkg, dev):
+    """reduce9r16: the same reduction inside each 16-lane row (the blend backward's second phase: one Gaussian per
+    row): every row delivers its own nine totals, nothing leaks between rows."""
+    lib = _dev_lib(pkg)
+    rng = np.random.default_rng(1)
+    for trial in range(4):
+        vals = rng.integers(-500, 500, size=(9, 64)).astype(np.float32)
+        if trial == 0:
+            vals = np.array([[1000.0 * (k + 1) + l for l in range(64)] for k in range(9)], np.float32)
+        if trial == 1:
+            vals[:, 16:32] = 0.0                                            # an empty row stays exactly zero
+        inp = torch.from_numpy(vals).to(dev)
+        out = torch.zeros(64, device=dev)
+        slots = torch.zeros(64, dtype=torch.int32, device=dev)
+        assert lib.cugsdbg_reduce9r16(C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()),
+                                      C.c_void_p(slots.data_ptr()), C.c_void_p(0)) == 0
+        torch.cuda.synchronize()
+        o, s = out.cpu().numpy(), slots.cpu().numpy()
+        for row in range(4):
+            sl = s[row * 16:(row + 1) * 16]
+            assert sorted(sl[sl >= 0].tolist()) == list(range(9))
+            want = vals[:, row * 16:(row + 1) * 16].sum(1)
+            for r in range(16):
+                if sl[r] >= 0:
+                    assert o[row * 16 + r] == want[sl[r]], (trial, row, r, sl[r])
+
+
 def test_rcp_of_one_is_exactly_one(pkg, dev):
     lib = _dev_lib(pkg)
     x = torch.tensor([1.0, 0.5, 2.0, 0.25, 0.01, 0.99, 1e-5], dtype=torch.float32, device=dev)
