@@ -39,7 +39,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
     typedef float v2f __attribute__((ext_vector_type(2)));
     float T = 1.0f, C0 = 0.0f;
     v2f C12 = {0.0f, 0.0f};                             // green/blue as one packed-fp32 accumulator (v_pk_fma_f32)
-    int count = 0;
+    float count = 0.0f;                                 // contributors: a float counter (exact below 2^24 per tile list)
     float open = inside ? 1.0f : 0.0f;                  // 1 while the pixel still blends, 0 once T < 1/255
     bool wave_done = (__ballot(open != 0.0f) == 0ull);
 
@@ -68,14 +68,18 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
                     const float4 g0 = rp[0], g1 = rp[1];                    // wave-uniform address: broadcast
                     const float o = rp[2].x;
                     PixelEval e;
-                    const float al = pixel_alpha(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, o, open, e);
+                    // decisions as 0/1 floats (v_fma ... clamp, cugs_raster_common.h): no v_cmp / v_cndmask pairs
+                    const float alpha = pixel_alpha_raw(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, o, open, e);
+                    const float passf = passes_alpha_min(alpha);           // alpha >= 1/255 (forward.cu:141)
+                    const float al = alpha * passf;
                     // al == 0 (skipped or finished pixel) leaves C, T and count untouched exactly
                     const float weight = al * T;
                     C0 = fmaf(weight, g1.y, C0);
                     C12 = __builtin_elementwise_fma((v2f){weight, weight}, (v2f){g1.z, g1.w}, C12);   // record words 6,7: an aligned pair
                     T *= (1.0f - al);
-                    count += (al != 0.0f) ? 1 : 0;
-                    open = (T < (1.0f / 255.0f)) ? 0.0f : open;             // only a passing Gaussian can lower T
+                    count += passf;
+                    open *= passes_alpha_min(T);                            // T < 1/255 -> done (forward.cu:150-156): the same
+                                                                            // threshold; only a passing Gaussian can lower T
                     if (__ballot(open != 0.0f) == 0ull) { wave_done = true; break; }
                 }
             }
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
         out_color[pix * 3 + 1] = fmaf(T, geo.bg1, C12.x);
         out_color[pix * 3 + 2] = fmaf(T, geo.bg2, C12.y);
         out_final_T[pix] = T;
-        out_n_contrib[pix] = count;
+        out_n_contrib[pix] = (int)count;
     }
 }
 
