@@ -113,6 +113,22 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
                               settings.background, n, packed=proj.packed, unpack=False)
     ev[4].record()
     d_means = torch.empty((n, 2), dtype=torch.float32, device=g.device)
+    if opt is not None and not do_allreduce:
+        # single GPU: the optimizer step rides in the projection backward (cugs_project_backward_adam) - same bits
+        # as project_backward + FusedAdam.step, 472 B/Gaussian less traffic (tests/test_gpu_parity.py)
+        import ctypes as C
+        adam = opt.begin_fused_step()
+        cam_abi = cam.to_abi()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        pkg._lib.check(pkg._lib.lib.cugs_project_backward_adam(
+            n, int(model.sh_coeffs.shape[2]), deg, P(model.positions), P(model.rotations), P(model.scales),
+            P(model.opacities), P(model.sh_coeffs), P(proj.radii), P(proj.rgb), C.byref(cam_abi),
+            float(settings.scale_modifier), P(rb.grad_accum), C.byref(adam), P(d_means),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cugs_project_backward_adam")
+        ev[5].record()
+        if sampled:
+            events.append(ev)
+        return srt.total_pairs, fwd, pkg.BackwardOutput(None, None, None, None, None, d_means)
     compact = do_allreduce and exchange == "compact"
     gated = torch.empty((n, 3), dtype=torch.float32, device=g.device) if compact else None
     flat = torch.empty((11 * n,), dtype=torch.float32, device=g.device) if compact else None

@@ -31,6 +31,12 @@ class AdamGroup(C.Structure):
                 ("n", C.c_int64), ("lr", C.c_float), ("reserved", C.c_float)]
 
 
+class AdamFused(C.Structure):
+    """struct cugs_adam_fused."""
+    _fields_ = [("m", C.c_void_p * 5), ("v", C.c_void_p * 5), ("lr", C.c_float * 5), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("bc1", C.c_float), ("bc2", C.c_float)]
+
+
 class DensifyArray(C.Structure):
     """struct cugs_densify_array."""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_floats", C.c_int32), ("mode", C.c_int32)]
@@ -64,6 +70,8 @@ SIGNATURES = {
                                      _P, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
     "cugs_project_backward": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Camera), _F,
                                    _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cugs_project_backward_adam": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Camera), _F, _P,
+                                        C.POINTER(AdamFused), _P, _P]),
     "cugs_sh_backward_views": (_I, [_I, _L, _I, _P, _I, _P, C.POINTER(C.c_float), _P, _P]),
     "cugs_adam_bias_correction": (None, [_F, _F, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cugs_fused_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),

@@ -22,7 +22,11 @@ namespace {
 
 constexpr int RADIX = 256;
 constexpr int IPT = 16;                           // items per thread
-constexpr int CHUNK = CUGS_BLOCK * IPT;           // 4096 items per workgroup
+constexpr int CHUNK_MIN = CUGS_BLOCK * IPT;       // 4096 items per workgroup: depth sort; sizes the histogram buffers
+#ifndef CUGS_PAIR_CHUNK_MULT
+#define CUGS_PAIR_CHUNK_MULT 1
+#endif
+constexpr int CHUNK_PAIR = CUGS_PAIR_CHUNK_MULT * CHUNK_MIN;   // pair-level passes (8192 / 16384: 4 % / 30 % slower, profiles/README.md)
 constexpr int FILL_CHUNK = CUGS_BLOCK;            // Gaussians per workgroup in scan/fill (one per thread)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -66,7 +70,7 @@ SortWsN carve_n(void* base, int64_t n) {
     for (int i = 0; i < 2; ++i) w.rect[i] = c.take<int4>((size_t)n);
     w.tot = c.take<uint32_t>(RADIX);
     w.blocksum = c.take<uint32_t>((size_t)nblocks_for(n, FILL_CHUNK) + 2);
-    w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, CHUNK) + 1));
+    w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, CHUNK_MIN) + 1));
     w.bytes = c.off;
     return w;
 }
@@ -75,7 +79,7 @@ SortWsP carve_p(void* base, int64_t pairs) {
     SortWsP w;
     for (int i = 0; i < 2; ++i) w.ptile[i] = c.take<uint32_t>((size_t)pairs);     // sized for the u32 case
     for (int i = 0; i < 2; ++i) w.pidx[i] = c.take<uint32_t>((size_t)pairs);
-    w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(pairs, CHUNK) + 1));
+    w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(pairs, CHUNK_MIN) + 1));
     w.bytes = c.off;
     return w;
 }
@@ -157,7 +161,7 @@ __device__ __forceinline__ uint32_t live_count(uint32_t count, const unsigned lo
 
 // ctl: when given, block 0 hands the Q12 counter k_fill_pairs has finished adding to (ctl[0]) over to
 // k_tile_ranges (ctl[1]) and re-arms it, so that cugs_sort_pairs may be repeated on one count.
-template <typename K, int NT>
+template <typename K, int NT, int CHUNK>
 __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, uint32_t count_or_cap,
                                                    const unsigned long long* __restrict__ dev_count, int shift,
                                                    uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(uint32_t* __rest
 // array.  NB: digit width (the match-any needs one ballot per digit bit).  NT: threads per workgroup -
 // 256 for the pair-level passes (thousands of workgroups), 1024 for the depth sort, whose 4096-item
 // chunks are too few to fill the chip with 4 waves each.
-template <typename K, bool IOTA, int NB, int NT, bool ARANK>
+template <typename K, bool IOTA, int NB, int NT, bool ARANK, int CHUNK>
 __global__ __launch_bounds__(NT) void k_radix_scatter(
     const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count_or_cap,
     const unsigned long long* __restrict__ dev_count, int shift, uint32_t mask_rt, const uint32_t* __restrict__ hist,
@@ -595,12 +599,12 @@ constexpr int rank_mode() { return 0; }            // ballot ranking: defined by
 #endif
 
 
-template <typename K, bool IOTA, int NT>
+template <typename K, bool IOTA, int NT, int CHUNK>
 int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned long long* dev_count, int shift, int bits,
                uint32_t* hist, uint32_t* tot, K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st) {
     const uint32_t nblk = nblocks_for(count, CHUNK);
     if (!hist_done) {
-        hipLaunchKernelGGL((k_radix_hist<K, NT>), dim3(nblk), dim3(NT), 0, st, kin, count, dev_count, shift,
+        hipLaunchKernelGGL((k_radix_hist<K, NT, CHUNK>), dim3(nblk), dim3(NT), 0, st, kin, count, dev_count, shift,
                            (1u << bits) - 1u, hist, nblk, ctl);
         CUGS_LAUNCH_CHECK();
     }
@@ -608,14 +612,14 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
     CUGS_LAUNCH_CHECK();
 #ifdef CUGS_DEV
     if (rank_mode() == 1) {               // digit width only matters to the ballot ranking: one instantiation
-        hipLaunchKernelGGL((k_radix_scatter<K, IOTA, 8, NT, true>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count,
+        hipLaunchKernelGGL((k_radix_scatter<K, IOTA, 8, NT, true, CHUNK>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count,
                            shift, (1u << bits) - 1u, hist, tot, nblk, kout, vout);
         CUGS_LAUNCH_CHECK();
         return 0;
     }
 #endif
 #define CUGS_SCATTER(NB)                                                                                          \
-    hipLaunchKernelGGL((k_radix_scatter<K, IOTA, NB, NT, false>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count, \
+    hipLaunchKernelGGL((k_radix_scatter<K, IOTA, NB, NT, false, CHUNK>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count, \
                        shift, 0u, hist, tot, nblk, kout, vout)
     switch (bits) {
         case 1: CUGS_SCATTER(1); break;
@@ -662,7 +666,7 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         const int shift = p * per;
         const int b = (bits - shift) < per ? (bits - shift) : per;
         uint32_t* vout = (p == npass - 1) ? vals_final : tv[cur ^ 1];
-        rc = radix_pass<K, false, 512>(tk[cur], tv[cur], up, dev_count, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, false,
+        rc = radix_pass<K, false, 512, CHUNK_PAIR>(tk[cur], tv[cur], up, dev_count, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, false,
                                        p == 0 ? ctl : nullptr, st);   // 512 threads: measured best of 256/512/1024
         if (rc) return rc;
         cur ^= 1;
@@ -682,10 +686,10 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
                        means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1], ws.rect[0]);
     CUGS_LAUNCH_CHECK();
     int rc;
-    if ((rc = radix_pass<uint32_t, true, 1024>(ws.dkey[1], nullptr, un, nullptr, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
-    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[0], ws.dval[0], un, nullptr, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
-    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[1], ws.dval[1], un, nullptr, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
-    if ((rc = radix_pass<uint32_t, false, 1024>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN>(ws.dkey[1], nullptr, un, nullptr, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[1], ws.dval[1], un, nullptr, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+    if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
     // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
     hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],

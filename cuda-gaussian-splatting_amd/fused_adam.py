@@ -104,6 +104,29 @@ class FusedAdam:
     def get_lr(self, group: ParamGroup) -> float:
         return self.learning_rates_[int(group)]
 
+    def begin_fused_step(self):
+        """The optimizer half of cugs_project_backward_adam (render_backward(..., fused_adam=self)): counts the
+        step and returns the C struct with the moments, learning rates and bias corrections.  The update itself
+        happens inside the projection backward, on the model this optimizer was built for, which must be
+        contiguous float32 (the kernel writes the parameters in place)."""
+        from ._lib import AdamFused
+        self.step_count_ += 1
+        bc1, bc2 = C.c_float(), C.c_float()
+        lib.cugs_adam_bias_correction(self.config_.beta1, self.config_.beta2, self.step_count_,
+                                      C.byref(bc1), C.byref(bc2))
+        a = AdamFused()
+        for i, nm in enumerate(self._names):
+            p = getattr(self.model_, nm)
+            if not (p.is_cuda and p.is_contiguous() and p.dtype == torch.float32 and self.m_[i].is_contiguous()
+                    and self.v_[i].is_contiguous()):
+                raise RuntimeError("FusedAdam: the fused step needs contiguous float32 CUDA parameters and moments")
+            a.m[i], a.v[i] = self.m_[i].data_ptr(), self.v_[i].data_ptr()
+            a.lr[i] = float(self.learning_rates_[i])
+        a.beta1, a.beta2, a.eps = self.config_.beta1, self.config_.beta2, self.config_.eps
+        a.bc1, a.bc2 = bc1.value, bc2.value
+        self.grads_ = [None] * self.kNumGroups
+        return a
+
     def step(self) -> None:
         self.step_count_ += 1
         bc1, bc2 = C.c_float(), C.c_float()

@@ -399,10 +399,14 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings) -
 def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: GaussianModel,
                     camera: CameraInfo, settings: RenderSettings,
                     dL_drgb_gated_out: Optional[torch.Tensor] = None,
-                    geom_flat: Optional[torch.Tensor] = None) -> BackwardOutput:
+                    geom_flat: Optional[torch.Tensor] = None, fused_adam=None) -> BackwardOutput:
     """`dL_drgb_gated_out` ([N,3], optional, not in the reference): when given, the per-view SH gradient
     is NOT materialised (dL_dsh_coeffs is None) and the gated colour gradient is written there instead,
-    for parallel.exchange_gradients() to rebuild the summed SH gradient after the all-gather."""
+    for parallel.exchange_gradients() to rebuild the summed SH gradient after the all-gather.
+    `fused_adam` (a FusedAdam built on `model`, optional, not in the reference): single-GPU training - the
+    projection backward applies the optimizer step to the model IN PLACE (cugs_project_backward_adam) and the
+    five parameter gradients are never materialised (they are None in the result; dL_dmeans_2d is returned).
+    Equivalent, bit for bit, to render_backward + apply_gradients + step."""
     _torch_check(dL_dcolor.is_cuda, "dL_dcolor must be on CUDA device")
     _torch_check(dL_dcolor.dim() == 3 and dL_dcolor.shape[2] == 3, "dL_dcolor must be [H, W, 3]")
     n = model.num_gaussians()
@@ -418,6 +422,19 @@ def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: Ga
                             render_out.final_T, render_out.n_contrib, camera.width, camera.height,
                             settings.background, n, packed=render_out.packed, unpack=False)
     d_means_2d = torch.empty((n, 2), **f)
+    if fused_adam is not None:
+        _torch_check(fused_adam.model_ is model, "fused_adam must have been built on this model")
+        _torch_check(dL_drgb_gated_out is None and geom_flat is None,
+                     "the fused optimizer step is for single-GPU training (no gradient exchange)")
+        adam = fused_adam.begin_fused_step()
+        cam = camera.to_abi()
+        check(lib.cugs_project_backward_adam(n, int(model.sh_coeffs.shape[2]), active_degree, _ptr(model.positions),
+                                             _ptr(model.rotations), _ptr(model.scales), _ptr(model.opacities),
+                                             _ptr(model.sh_coeffs), _ptr(render_out.radii.contiguous()),
+                                             _ptr(render_out.rgb.contiguous()), C.byref(cam),
+                                             float(settings.scale_modifier), _ptr(rb.grad_accum), C.byref(adam),
+                                             _ptr(d_means_2d), _stream(dev)), "cugs_project_backward_adam")
+        return BackwardOutput(None, None, None, None, None, d_means_2d)
     pb = project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
                           model.opacities, model.sh_coeffs, render_out.radii, camera, active_degree,
                           settings.scale_modifier, grad_accum=rb.grad_accum, rgb_clamped=render_out.rgb,

@@ -166,6 +166,28 @@ int cugs_project_backward(int64_t n, int num_coeffs, int active_degree,
                           float* dL_dopacities, float* dL_dsh_coeffs, float* dL_dmeans_2d_out,
                           float* dL_drgb_gated_out, void* stream);
 
+/* ---- a8+a9+a11 in one launch (single-GPU training; trainer.cpp:228-242 calls render_backward, then
+ * FusedAdam::apply_gradients + step): the projection/SH backward applies k_fused_adam's update
+ * (fused_adam.cu:44-76) to each Gaussian's own parameters as soon as its gradients exist, so the five gradient
+ * tensors (236 B/Gaussian at degree 3) are neither written nor read back by an optimizer launch.  Same
+ * arithmetic in the same order as cugs_project_backward followed by cugs_fused_adam_groups: identical bits.
+ * The parameters are updated IN PLACE; the 2-D gradients come from grad_accum, the ReLU gate from rgb_clamped
+ * (both required).  adam_host: moments and learning rates in ParamGroup order {positions, sh_coeffs,
+ * opacities, scales, rotations} (lr_schedule.hpp:23-29), bc1/bc2 from cugs_adam_bias_correction.  Not for
+ * data-parallel training: there the gradients must be exchanged between backward and optimizer. */
+typedef struct cugs_adam_fused {
+    float* m[5];
+    float* v[5];
+    float lr[5];
+    float beta1, beta2, eps, bc1, bc2;
+} cugs_adam_fused;
+int cugs_project_backward_adam(int64_t n, int num_coeffs, int active_degree, float* positions,
+                               float* rotations, float* scales, float* opacities, float* sh_coeffs,
+                               const int32_t* radii, const float* rgb_clamped,
+                               const cugs_camera* camera_host, float scale_modifier,
+                               const float* grad_accum, const cugs_adam_fused* adam_host,
+                               float* dL_dmeans_2d_out, void* stream);
+
 /* ---- data-parallel extension (no counterpart in the single-GPU reference) ----------
  * dL_dsh[i] = sum over views v of gated_rgb_views[v][i] (x) Y(normalize(positions[i] - centre_v)),
  * accumulated in view order.  gated_rgb_views: [num_views][n][3] (the all-gather of every rank's

@@ -453,3 +453,55 @@ def test_compact_exchange_equals_sum_of_views(pkg, orc, dev):
     got = pkg.sh_backward_views(deg, model.positions, torch.stack(gated_all), centres, 16)
     assert max_err_over_max(np_(got), np_(full_sh)) <= 1e-5
     assert max_err_over_max(np_(pos_sum), np_(full_pos)) <= 1e-5
+
+
+@pytest.mark.parametrize("n,w,h,deg", [(3000, 200, 150, 3), (777, 96, 64, 1), (1000, 128, 96, 0)])
+def test_fused_adam_backward_equals_backward_then_adam(pkg, dev, n, w, h, deg):
+    """cugs_project_backward_adam (a8 + a9 + a11 in one launch, single-GPU training): the model, the moments and
+    dL_dmeans_2d after render_backward(..., fused_adam=opt) must equal render_backward + apply_gradients + step
+    BIT FOR BIT over three steps (moments carried, bias corrections advancing) - same arithmetic, same order;
+    only the blend backward's atomics may reorder sums, so both paths consume the SAME accumulator rows."""
+    arrays, cam = _scene(pkg, n, w, h, deg, seed=n, mu_s=-3.7)
+    settings = pkg.RenderSettings(background=[0.2, 0.1, 0.3], active_sh_degree=deg)
+    g = torch.from_numpy(pkg.scene.make_dl_dcolor(w, h, seed=n + 1) * 3000.0).to(dev)    # gradients large enough to move parameters
+    ma, mb = pkg.scene.to_model(arrays, dev), pkg.scene.to_model(arrays, dev)
+    oa, ob = pkg.FusedAdam(ma), pkg.FusedAdam(mb)
+    R = pkg.rasterizer
+    names = ("positions", "sh_coeffs", "opacities", "scales", "rotations")
+    for step in range(3):
+        out = pkg.render(ma, cam, settings)
+        assert all(torch.equal(getattr(ma, k), getattr(mb, k)) for k in names)
+        rb = R.rasterize_backward(g, out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges,
+                                  out.gaussian_indices, out.final_T, out.n_contrib, w, h, settings.background, n,
+                                  packed=out.packed, unpack=False)
+        # path A: projection backward -> five gradient tensors -> FusedAdam.step
+        dm_a = torch.empty((n, 2), device=dev)
+        pb = R.project_backward(None, None, None, None, ma.positions, ma.rotations, ma.scales, ma.opacities,
+                                ma.sh_coeffs, out.radii, cam, deg, settings.scale_modifier, grad_accum=rb.grad_accum,
+                                rgb_clamped=out.rgb, dL_dmeans_2d_out=dm_a)
+        oa.apply_gradients(pkg.BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
+                                              pb.dL_dsh_coeffs, dm_a))
+        oa.step()
+        # path B: the fused launch on the same accumulator rows
+        import ctypes as C
+        from cugs_amd._lib import check, lib
+        adam = ob.begin_fused_step()
+        dm_b = torch.empty((n, 2), device=dev)
+        cam_abi = cam.to_abi()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        check(lib.cugs_project_backward_adam(n, int(mb.sh_coeffs.shape[2]), deg, P(mb.positions), P(mb.rotations),
+                                             P(mb.scales), P(mb.opacities), P(mb.sh_coeffs), P(out.radii), P(out.rgb),
+                                             C.byref(cam_abi), float(settings.scale_modifier), P(rb.grad_accum),
+                                             C.byref(adam), P(dm_b), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "cugs_project_backward_adam")
+        assert torch.equal(dm_a, dm_b)
+        for i, k in enumerate(names):
+            assert torch.equal(getattr(ma, k), getattr(mb, k)), (step, k)
+            assert torch.equal(oa.m_[i], ob.m_[i]) and torch.equal(oa.v_[i], ob.v_[i]), (step, k)
+        assert oa.step_count_ == ob.step_count_ == step + 1
+    assert not torch.equal(ma.positions, torch.from_numpy(arrays["positions"]).to(dev))       # the model moved
+    # and through the host surface: render_backward(..., fused_adam=) returns only dL_dmeans_2d
+    out = pkg.render(mb, cam, settings)
+    res = pkg.render_backward(g, out, mb, cam, settings, fused_adam=ob)
+    assert res.dL_dpositions is None and res.dL_dsh_coeffs is None and res.dL_dmeans_2d.shape == (n, 2)
+    assert ob.step_count_ == 4
