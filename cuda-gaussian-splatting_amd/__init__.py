@@ -20,5 +20,5 @@ from .fused_adam import (AdamConfig, FusedAdam, ParamGroup, PositionLRConfig,  #
 from .loss import combined_loss, combined_loss_and_grad, l1_loss, ssim, ssim_loss  # noqa: F401
 from .densification import DensificationConfig, DensificationController, DensificationStats  # noqa: F401
 from .ply_io import read_gaussian_ply, restore_optimizer, write_gaussian_ply  # noqa: F401
-from .views import ViewCache, image_to_float, load_image_resized, load_image_u8  # noqa: F401
+from .views import StreamedViewCache, ViewCache, image_to_float, load_image_resized, load_image_u8  # noqa: F401
 from . import parallel, scene  # noqa: F401

@@ -94,3 +94,89 @@ class ViewCache:
     def target(self, index: int, width: int, height: int) -> torch.Tensor:
         """The tensor trainer.cpp:186-198 builds: the view at the camera's resolution, float [H, W, 3]."""
         return image_to_float(self._views[index], width, height)
+
+
+class StreamedViewCache:
+    """The same targets for view sets that do NOT fit in HBM (SURVEY §8f N4 "decode once, cache, prefetch"): the
+    decoded 8-bit views stay in PINNED host memory and travel to the device one iteration ahead of their use, on a
+    side stream, into a small ring of device slots - 3 B/pixel over PCIe hidden under the previous iteration's
+    render instead of the reference's decode + CPU resize + 12 B/pixel upload in the iteration's own critical
+    path (training/trainer.cpp:186-198).  target() gives bit-identical tensors to ViewCache.target().
+
+        cache.prefetch(next_index)                 # right after sampling the next view, before this render
+        tgt = cache.target(index, W, H)            # waits (on the device) only for that view's upload
+
+    A view that was not prefetched is uploaded on demand (correct, just not overlapped).  Slot reuse is ordered
+    by events both ways: an upload waits for the last kernel that read the slot, a reader waits for the upload."""
+
+    def __init__(self, device, slots: int = 2):
+        _torch_check(slots >= 2, "at least two slots (one in use, one in flight)")
+        self.device = torch.device(device)
+        self._host: List[torch.Tensor] = []                    # pinned uint8 [H, W, 3]
+        self._slot_buf: List[torch.Tensor] = [torch.empty(0, dtype=torch.uint8, device=self.device) for _ in range(slots)]
+        self._slot_view = [-1] * slots                         # which view a slot holds (or is receiving)
+        self._slot_ready: List[torch.cuda.Event] = [None] * slots      # upload finished (recorded on the copy stream)
+        self._slot_free: List[torch.cuda.Event] = [None] * slots       # last reader queued (recorded on its stream)
+        self._next = 0
+        self._copy_stream = torch.cuda.Stream(device=self.device)
+        self.uploads = 0                                       # statistics: total uploads / of which on demand
+        self.misses = 0
+
+    def add(self, image_u8) -> int:
+        t = torch.as_tensor(image_u8)
+        _torch_check(t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3, "view must be uint8 [H, W, 3]")
+        self._host.append(t.contiguous().cpu().pin_memory())
+        return len(self._host) - 1
+
+    def add_file(self, path) -> int:
+        return self.add(load_image_u8(path))
+
+    def __len__(self) -> int:
+        return len(self._host)
+
+    def size(self, index: int) -> Tuple[int, int]:
+        v = self._host[index]
+        return int(v.shape[1]), int(v.shape[0])
+
+    def host_bytes(self) -> int:
+        return sum(int(v.numel()) for v in self._host)
+
+    def _slot_of(self, index: int) -> int:
+        for s, v in enumerate(self._slot_view):
+            if v == index:
+                return s
+        return -1
+
+    def prefetch(self, index: int) -> None:
+        """Queue the upload of view `index` into the next ring slot (no-op if it is already resident or in flight)."""
+        if self._slot_of(index) >= 0:
+            return
+        s = self._next
+        self._next = (self._next + 1) % len(self._slot_buf)
+        src = self._host[index]
+        if self._slot_buf[s].numel() < src.numel():
+            self._slot_buf[s] = torch.empty(int(src.numel()), dtype=torch.uint8, device=self.device)
+        with torch.cuda.stream(self._copy_stream):
+            if self._slot_free[s] is not None:
+                self._copy_stream.wait_event(self._slot_free[s])        # the slot's last reader has finished
+            self._slot_buf[s][:src.numel()].copy_(src.reshape(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        self._slot_view[s], self._slot_ready[s] = index, ev
+        self.uploads += 1
+
+    def target(self, index: int, width: int, height: int) -> torch.Tensor:
+        s = self._slot_of(index)
+        if s < 0:                                               # not prefetched: upload now, same path
+            self.misses += 1
+            self.prefetch(index)
+            s = self._slot_of(index)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self._slot_ready[s])
+        src = self._host[index]
+        view = self._slot_buf[s][:src.numel()].view(src.shape)
+        out = image_to_float(view, width, height)
+        free = torch.cuda.Event()
+        free.record(cur)
+        self._slot_free[s] = free
+        return out

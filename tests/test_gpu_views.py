@@ -40,3 +40,38 @@ def test_cache_and_file_helpers(pkg, vo, dev, tmp_path):
     assert tuple(full.shape) == (6, 8, 3)
     with pytest.raises(RuntimeError, match="Invalid target dimensions"):
         cache.target(0, 0, 5)
+
+
+def test_prefetched_targets_equal_cached_targets(pkg, dev):
+    """StreamedViewCache (views in pinned host memory, uploaded one iteration ahead on a side stream into a
+    two-slot device ring): every target is bit-identical to the device-resident ViewCache's, whatever the order,
+    with prefetch hits, on-demand misses and slot reuse (8 views through 2 slots, different sizes)."""
+    rng = np.random.default_rng(3)
+    sizes = [(64, 48), (640, 360), (37, 53), (1920, 1080), (5, 7), (320, 200), (64, 48), (800, 600)]
+    views = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for w, h in sizes]
+    resident, streamed = pkg.ViewCache(dev), pkg.StreamedViewCache(dev, slots=2)
+    for v in views:
+        assert resident.add(v) == streamed.add(v)
+    assert len(streamed) == 8 and streamed.host_bytes() == resident.bytes() and streamed.size(3) == (1920, 1080)
+    tw, th = 480, 270
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 3, 3, 1, 6, 0]
+    streamed.prefetch(order[0])
+    for k, idx in enumerate(order):
+        if k + 1 < len(order):
+            streamed.prefetch(order[k + 1])                     # next view travels while this one is consumed
+        got = streamed.target(idx, tw, th)
+        # work on the compute stream between iterations, as a render would be
+        busy = torch.ones((512, 512), device=dev) @ torch.ones((512, 512), device=dev)
+        want = resident.target(idx, tw, th)
+        assert torch.equal(got, want), (k, idx)
+        del busy
+    assert streamed.misses == 0 and streamed.uploads >= 8
+    # on-demand path: no prefetch at all
+    cold = pkg.StreamedViewCache(dev, slots=2)
+    for v in views[:3]:
+        cold.add(v)
+    for idx in (2, 0, 1, 0):
+        assert torch.equal(cold.target(idx, 100, 80), resident.target(idx, 100, 80))
+    assert cold.misses == 3                                      # the last access finds view 0 still in its slot
+    # same-size native-resolution target (no resize) through the ring
+    assert torch.equal(streamed.target(3, 1920, 1080), resident.target(3, 1920, 1080))
