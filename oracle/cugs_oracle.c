@@ -857,6 +857,7 @@ int orc_project_sh_forward_mt(int nthreads, int n, int degree, int num_coeffs,
                               float* cov_2d_inv, int32_t* radii, int32_t* tiles_touched,
                               float* opacities_act, float* dirs, float* rgb) {
     if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1 && n / nthreads < 2048) nthreads = n / 2048 > 1 ? n / 2048 : 1;   /* a thread's share must outweigh its wake-up */
     int chunk = (n + nthreads - 1) / nthreads;
 #pragma omp parallel for num_threads(nthreads) schedule(static, 1)
     for (int t = 0; t < nthreads; ++t) {
