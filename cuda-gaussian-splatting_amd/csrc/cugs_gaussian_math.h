@@ -259,8 +259,10 @@ __device__ __forceinline__ float sh_colour(int degree, Ptr c, int stride, V3 d) 
 
 // ---------------------------------------------------------------------------------------
 // Packed projected-Gaussian record consumed by the blend kernels (CUGS_PACKED_STRIDE floats):
-//   [0] mx  [1] my  [2] a  [3] b | [4] c  [5] r  [6] g  [7] bl | [8] opacity  [9] tau  [10] 0  [11] 0
-// (words 10, 11 are spare in HBM; the blend kernels' LDS copy keeps the Gaussian index in word 10)
+//   [0] mx  [1] my  [2] a  [3] b | [4] c  [5] opacity  [6] tau  [7] 0 | [8] r  [9] 0  [10] g  [11] bl
+// Everything the per-wave cull reads (mean, Sigma'^-1, tau) sits in the first two 16-byte chunks; the colour chunk
+// keeps green/blue as an aligned pair (v_pk_fma_f32 in the forward blend).  Word 7 is spare in HBM; the blend
+// kernels' LDS copy keeps the Gaussian index there.
 // tau = ln(255 * opacity) is the largest -power at which alpha can still reach 1/255; it only
 // feeds the CONSERVATIVE per-wave cull (see cugs_raster_common.h), never a result, so the
 // ocml logf here does not affect parity.  tau < 0 marks "can never contribute" (opacity < 1/255,
@@ -271,6 +273,6 @@ __device__ __forceinline__ void write_packed(float* packed, int64_t idx, float m
     float tau = (opacity >= (1.0f / 255.0f)) ? logf(255.0f * opacity) : -1.0f;
     float4* dst = reinterpret_cast<float4*>(packed + idx * CUGS_PACKED_STRIDE);
     dst[0] = make_float4(mx, my, inv.a, inv.b);
-    dst[1] = make_float4(inv.c, r, g, b);
-    dst[2] = make_float4(opacity, tau, 0.0f, 0.0f);
+    dst[1] = make_float4(inv.c, opacity, tau, 0.0f);
+    dst[2] = make_float4(r, 0.0f, g, b);
 }

@@ -35,7 +35,7 @@ struct RasterSrc {
 };
 
 // Stage list entry `li` (if < end) into LDS slot threadIdx.x.  The LDS copy of the record carries the
-// Gaussian index (as bits) in word 10 in place of 1/a, so that the backward's scatter address comes
+// Gaussian index (as bits) in its spare word 7, so that the backward's scatter address comes
 // with the same 16-byte read as the opacity.  Returns the Gaussian index (or -1).
 template <bool PACKED>
 __device__ __forceinline__ int stage_record(const RasterSrc& s, int li, int end, float4* s_rec) {
@@ -48,17 +48,17 @@ __device__ __forceinline__ int stage_record(const RasterSrc& s, int li, int end,
     } else {
         const float a = s.cov_2d_inv[g * 3 + 0], c = s.cov_2d_inv[g * 3 + 2], o = s.opa[g];
         r0 = make_float4(s.means_2d[g * 2 + 0], s.means_2d[g * 2 + 1], a, s.cov_2d_inv[g * 3 + 1]);
-        r1 = make_float4(c, s.rgb[g * 3 + 0], s.rgb[g * 3 + 1], s.rgb[g * 3 + 2]);
-        r2 = make_float4(o, (o >= (1.0f / 255.0f)) ? logf(255.0f * o) : -1.0f, 0.0f, 0.0f);
+        r1 = make_float4(c, o, (o >= (1.0f / 255.0f)) ? logf(255.0f * o) : -1.0f, 0.0f);
+        r2 = make_float4(s.rgb[g * 3 + 0], 0.0f, s.rgb[g * 3 + 1], s.rgb[g * 3 + 2]);
     }
-    r2.z = __int_as_float(g);
+    r1.w = __int_as_float(g);
     s_rec[threadIdx.x * CUGS_REC_F4 + 0] = r0;
     s_rec[threadIdx.x * CUGS_REC_F4 + 1] = r1;
     s_rec[threadIdx.x * CUGS_REC_F4 + 2] = r2;
     return g;
 }
 
-// Can the Gaussian in (r0, r1, r2) reach alpha >= 1/255 at ANY pixel centre of the rectangle of
+// Can the Gaussian in (r0, r1: the record's geometry chunks) reach alpha >= 1/255 at ANY pixel centre of the rectangle of
 // centres [qx0, qx0+wx] x [qy0, qy0+wy] (the wave's quad, or the bounding box of its pixels that are
 // still active: ActiveRect below)?  `false` only when certainly not.
 //
@@ -71,10 +71,10 @@ __device__ __forceinline__ int stage_record(const RasterSrc& s, int li, int end,
 // B = |a| X^2 + 2 |b| X Y + |c| Y^2 (X, Y the largest |offset|); q_min here carries a similar
 // error; ocml logf ~2 ulp; detexp 1 ulp.  The slack 0.01 tau + 0.05 + 4e-6 B dominates all of it
 // by orders of magnitude.  Any NaN makes the final comparison false -> not culled.
-__device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float4 r2, float qx0, float qy0,
+__device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float qx0, float qy0,
                                                float wx, float wy) {
     const float mx = r0.x, my = r0.y, a = r0.z, b = r0.w, c = r1.x;
-    const float tau = r2.y;
+    const float tau = r1.z;
     if (!(tau >= 0.0f)) return false;
     if (!(a > 0.0f && c > 0.0f)) return true;
     const float ia = __builtin_amdgcn_rcpf(a), ic = __builtin_amdgcn_rcpf(c);   // cull only: 1 ulp is irrelevant
@@ -88,8 +88,8 @@ __device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float4 r2, 
     // the horizontal one likewise (a point of a far edge is reached from the mean through a near edge, where q
     // is smaller).  Each at its clamped 1-D minimiser.
     const float xe = (lx > 0.0f) ? lx : hx, ye = (ly > 0.0f) ? ly : hy;          // the near edges (if outside)
-    const float yv = fminf(fmaxf(-b * xe * ic, ly), hy);
-    const float xv = fminf(fmaxf(-b * ye * ia, lx), hx);
+    const float yv = __builtin_amdgcn_fmed3f(-b * xe * ic, ly, hy);             // clamp (ly <= hy): one v_med3_f32
+    const float xv = __builtin_amdgcn_fmed3f(-b * ye * ia, lx, hx);             // a NaN input still reaches q through a, b, c
     const float qx = a * xe * xe + b2 * xe * yv + c * yv * yv;
     const float qy = a * xv * xv + b2 * xv * ye + c * ye * ye;
     const bool out_x = !((lx <= 0.0f) && (hx >= 0.0f)), out_y = !((ly <= 0.0f) && (hy >= 0.0f));

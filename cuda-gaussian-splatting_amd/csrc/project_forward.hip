@@ -173,8 +173,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
         s_cov[t * 3 + 0] = inv.a; s_cov[t * 3 + 1] = inv.b; s_cov[t * 3 + 2] = inv.c;
         const float tau = (opa >= (1.0f / 255.0f)) ? logf(255.0f * opa) : -1.0f;   // as write_packed
         s_pk[t * 3 + 0] = make_float4(mx, my, inv.a, inv.b);
-        s_pk[t * 3 + 1] = make_float4(inv.c, col[0], col[1], col[2]);
-        s_pk[t * 3 + 2] = make_float4(opa, tau, 0.0f, 0.0f);
+        s_pk[t * 3 + 1] = make_float4(inv.c, opa, tau, 0.0f);
+        s_pk[t * 3 + 2] = make_float4(col[0], 0.0f, col[1], col[2]);
         __syncthreads();
         if (t < 3 * CUGS_BLOCK / 4) {
             reinterpret_cast<float4*>(p.rgb + base * 3)[t] = reinterpret_cast<const float4*>(s_rgb)[t];

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         const float4* c4 = reinterpret_cast<const float4*>(&s_contrib[wave][h2][g2i * 4]);
         const float4 p01 = c4[0], p23 = c4[1];                                         // (weight, v3) x 4 pixels
         const float2 mean = *reinterpret_cast<const float2*>(&s_rec[rec]);
-        const float4 tail = s_rec[rec + 2];                                            // opacity, tau, index, 1/c
+        const float4 tail = s_rec[rec + 1];                                            // c, opacity, tau, index
         const float dy = py2 - mean.y;
         const float dx0 = px2 - mean.x, dx1 = dx0 + 1.0f, dx2 = dx0 + 2.0f, dx3 = dx0 + 3.0f;
         float t = p01.y * dx0;
@@ -140,12 +140,12 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         t = p23.w * dx3; A += p23.w; M1 += t; Mxx = fmaf(t, dx3, Mxx);
         RA = fmaf(p23.z, eA[3], RA); RB = fmaf(p23.z, eB[3], RB); R2 = fmaf(p23.z, e2[3], R2);
         // dL/dpower = v3 * opacity (alpha = opacity * e where the gate is open); dy is common to the four pixels
-        const float oA = tail.x * A;
-        M1 *= tail.x; Mxx *= tail.x;
+        const float oA = tail.y * A;
+        M1 *= tail.y; Mxx *= tail.y;
         const float M1y = dy * oA, Myy = dy * M1y, Mxy = dy * M1;
         const float total = reduce9r16(RA, RB, R2, A, M1, M1y, Mxx, Myy, Mxy, lane);
         if (slot2 >= 0 && h2 < cnt) {
-            const int g = __float_as_int(tail.z);
+            const int g = __float_as_int(tail.w);
             if (WIDE) {
                 atomicAdd(grad_accum + (int64_t)g * CUGS_GRAD_STRIDE + slot2, total);
             } else {
@@ -172,8 +172,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                 const ActiveRect ar = active_rect(__ballot(open != 0.0f), qx0, qy0);   // !wave_done => non-empty
                 bool hit = false;
                 if (j < batch_count)
-                    hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1],
-                                         s_rec[j * CUGS_REC_F4 + 2], ar.x0, ar.y0, ar.wx, ar.wy);
+                    hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1], ar.x0, ar.y0, ar.wx,
+                                         ar.wy);
                 unsigned long long mask = __ballot(hit);
                 if (STATS) st_tested += min(CUGS_WAVE, batch_count - sub * CUGS_WAVE);
                 while (mask != 0ull) {                                     // back to front: highest bit first
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                     const int bit = 63 - __builtin_clzll(mask);
                     mask &= ~(1ull << bit);
                     const int rec = (sub * CUGS_WAVE + bit) * CUGS_REC_F4;
-                    const float4 g0 = s_rec[rec], g1 = s_rec[rec + 1];
-                    const float o = s_rec[rec + 2].x;
+                    const float4 g0 = s_rec[rec], g1 = s_rec[rec + 1], col = s_rec[rec + 2];
+                    const float o = g1.y;
 
                     // ---- decisions (backward.cu:123-145) as 0/1 floats
                     PixelEval e;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                     const float rcp = __builtin_amdgcn_rcpf(1.0f - al);    // al <= 0.99; rcp(1) == 1 exactly
                     T *= rcp;                                              // T_before = T_after / (1 - alpha)
                     const float weight = al * T;
-                    const float G = fmaf(dC2, g1.w, fmaf(dC1, g1.z, dC0 * g1.y));
+                    const float G = fmaf(dC2, col.w, fmaf(dC1, col.z, dC0 * col.x));
                     const float gate = fmaf(T, G, -(rcp * D)) * gk;        // dL/dalpha, gated
                     D = fmaf(weight, G, D);
                     if (STATS) {

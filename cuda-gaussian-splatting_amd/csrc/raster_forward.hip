@@ -59,14 +59,14 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
                 const ActiveRect ar = active_rect(__ballot(open != 0.0f), qx0, qy0);   // !wave_done => non-empty
                 bool hit = false;
                 if (j < batch_count)
-                    hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1],
-                                         s_rec[j * CUGS_REC_F4 + 2], ar.x0, ar.y0, ar.wx, ar.wy);
+                    hit = may_touch_quad(s_rec[j * CUGS_REC_F4 + 0], s_rec[j * CUGS_REC_F4 + 1], ar.x0, ar.y0, ar.wx,
+                                         ar.wy);
                 unsigned long long mask = __ballot(hit);
                 while (mask != 0ull) {                                      // front to back
                     const float4* rp = s_rec + (sub * CUGS_WAVE + __builtin_ctzll(mask)) * CUGS_REC_F4;
                     mask &= mask - 1ull;
-                    const float4 g0 = rp[0], g1 = rp[1];                    // wave-uniform address: broadcast
-                    const float o = rp[2].x;
+                    const float4 g0 = rp[0], g1 = rp[1], col = rp[2];       // wave-uniform address: broadcast
+                    const float o = g1.y;
                     PixelEval e;
                     // decisions as 0/1 floats (v_fma ... clamp, cugs_raster_common.h): no v_cmp / v_cndmask pairs
                     const float alpha = pixel_alpha_raw(pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, o, open, e);
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
                     const float al = alpha * passf;
                     // al == 0 (skipped or finished pixel) leaves C, T and count untouched exactly
                     const float weight = al * T;
-                    C0 = fmaf(weight, g1.y, C0);
-                    C12 = __builtin_elementwise_fma((v2f){weight, weight}, (v2f){g1.z, g1.w}, C12);   // record words 6,7: an aligned pair
+                    C0 = fmaf(weight, col.x, C0);
+                    C12 = __builtin_elementwise_fma((v2f){weight, weight}, (v2f){col.z, col.w}, C12);   // record words 10,11: an aligned pair
                     T *= (1.0f - al);
                     count += passf;
                     open *= passes_alpha_min(T);                            // T < 1/255 -> done (forward.cu:150-156): the same
