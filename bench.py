@@ -358,10 +358,15 @@ def launcher_dry_run(args, world, rank):
     """The N-rank plumbing without a GPU (tests/test_bench_launcher.py): rendezvous over gloo, barrier, MAX over
     ranks of a per-rank number, one JSON line from rank 0."""
     import torch.distributed as dist
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)                                 # the backends' own chatter goes to stderr (see main)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.barrier()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": dist.get_world_size(), "max_over_ranks": float(t.item()),
                           "steps": args.steps, "warmup": args.warmup}), flush=True)
@@ -412,7 +417,13 @@ def main():
         else:
             print(json.dumps({"dry_run": True, "n_gpus": 1}), flush=True)
         return
+    stdout_fd = None
     if launched:
+        # RCCL (and gloo) write banners to stdout when a communicator comes up; the contract is ONE JSON line there,
+        # so file descriptor 1 points at stderr until rank 0 prints its line
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -563,6 +574,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pkg, orc, wl, arrays, cam, g_host, args.cpu_rows)
         if not args.no_parity and not forward_only and n_gpus == 1:
             out["parity"] = parity_probe(pkg, orc, dev)
+        if stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
     if launched:
         torch.distributed.barrier()

@@ -21,8 +21,8 @@ def test_self_launch_two_ranks_one_json_line():
     res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--launcher-dry-run"],
                          capture_output=True, text=True, timeout=300, env=_env())
     assert res.returncode == 0, res.stderr[-2000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]     # gloo itself chats on stdout
-    assert len(lines) == 1                                     # rank 0 only
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout                         # rank 0's JSON line and nothing else (no backend banners)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["max_over_ranks"] == 2.0 and out["steps"] == 3 and out["warmup"] == 1
 
