@@ -80,7 +80,11 @@ __device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float qx0, 
     const float ia = __builtin_amdgcn_rcpf(a), ic = __builtin_amdgcn_rcpf(c);   // cull only: 1 ulp is irrelevant
     const float lx = qx0 - mx, hx = lx + wx, ly = qy0 - my, hy = ly + wy;
     const bool inside = (lx <= 0.0f) && (hx >= 0.0f) && (ly <= 0.0f) && (hy >= 0.0f);
-    const float X = fmaxf(fabsf(lx), fabsf(hx)), Y = fmaxf(fabsf(ly), fabsf(hy));
+    // largest |offset| per axis: lx <= hx, so max(|lx|, |hx|) = max(-lx, hx) - ONE v_max_f32 (as C, fmaxf costs two
+    // more instructions that canonicalise its inputs; the values only scale the slack)
+    float X, Y;
+    asm("v_max_f32_e64 %0, -%1, %2" : "=v"(X) : "v"(lx), "v"(hx));
+    asm("v_max_f32_e64 %0, -%1, %2" : "=v"(Y) : "v"(ly), "v"(hy));
     const float B = a * X * X + 2.0f * fabsf(b) * X * Y + c * Y * Y;
     const float b2 = b + b;
     // q is convex with its minimum at the mean, so over a rectangle that does not contain the mean the minimum
