@@ -505,3 +505,28 @@ def test_fused_adam_backward_equals_backward_then_adam(pkg, dev, n, w, h, deg):
     res = pkg.render_backward(g, out, mb, cam, settings, fused_adam=ob)
     assert res.dL_dpositions is None and res.dL_dsh_coeffs is None and res.dL_dmeans_2d.shape == (n, 2)
     assert ob.step_count_ == 4
+
+
+def test_backward_with_clamped_alphas_and_tiny_images(pkg, orc, dev):
+    """Q2 (backward.cu:181-191): where opacity * e >= 0.99 the alpha is clamped, dL/dopacity and dL/dpower are zeroed
+    and dL/drgb still flows.  The standard scenes (opacity logits ~ N(0,1)) never reach the clamp, so a third of the
+    Gaussians here get logit +9 (sigmoid 0.99988): the clamp gate (`below_alpha_cap`) decides on thousands of
+    contributions.  Also the backward on 1-pixel / sliver images (the forward of these is in test_gpu_fullsize.py)."""
+    for n, w, h, mu_s, seed in ((6000, 320, 200, -3.4, 5), (60, 1, 1, -3.0, 6), (300, 17, 3, -1.5, 7)):
+        arrays = pkg.scene.make_gaussians(n, max(w, 8), max(h, 8), sh_degree=1, seed=seed, mu_s=mu_s)
+        arrays["opacities"][:: 3] = 9.0
+        cam = pkg.scene.make_camera(w, h)
+        model = pkg.scene.to_model(arrays, dev)
+        st = pkg.RenderSettings(background=[0.3, 0.1, 0.2], active_sh_degree=1)
+        out = pkg.render(model, cam, st)
+        ref = oracle_forward(orc, arrays, cam, bg=(0.3, 0.1, 0.2), degree=1)
+        assert np.array_equal(np_(out.n_contrib), ref["n_contrib"])
+        assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32))
+        if n == 6000:                                   # the clamp is really exercised: some pixel sees alpha == 0.99
+            assert float(ref["final_T"].min()) < 0.011 and int((ref["n_contrib"] == 1).sum()) > 0
+        g = pkg.scene.make_dl_dcolor(w, h, seed=seed)
+        grads = pkg.render_backward(torch.from_numpy(g).to(dev), out, model, cam, st)
+        refb = oracle_backward(orc, g, ref, arrays, cam, bg=(0.3, 0.1, 0.2))
+        for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs", "dL_dmeans_2d"):
+            got = np_(getattr(grads, name)).reshape(refb[name].shape)
+            assert max_err_over_max(got, refb[name]) <= GRAD_TOL, (n, name)
