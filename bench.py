@@ -115,9 +115,10 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     srt = R.sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, cam.width, cam.height,
                                      want_keys=False)
     ev[2].record()
+    accum = torch.empty((n, pkg._lib.GRAD_STRIDE), dtype=torch.float32, device=g.device)   # cleared by the forward blend
     blend = lambda s: R.rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
                                           s.gaussian_values_sorted, cam.width, cam.height, settings.background,
-                                          packed=proj.packed)
+                                          packed=proj.packed, zero_buf=accum)
     fwd = blend(srt)
     if isinstance(srt, R.PendingSort):
         srt, valid = srt.finish()
@@ -126,7 +127,7 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     ev[3].record()
     rb = R.rasterize_backward(g, proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
                               srt.gaussian_values_sorted, fwd.final_T, fwd.n_contrib, cam.width, cam.height,
-                              settings.background, n, packed=proj.packed, unpack=False)
+                              settings.background, n, packed=proj.packed, unpack=False, zeroed_accum=accum)
     ev[4].record()
     d_means = torch.empty((n, 2), dtype=torch.float32, device=g.device)
     if opt is not None and not do_allreduce:
@@ -388,6 +389,9 @@ def main():
                          "auto = time three steps of each before the warmup and keep the faster one")
     ap.add_argument("--rehearse-calibration", action="store_true",
                     help="run the auto exchange calibration even with a single rank (one-GPU rehearsal of the N>1 path)")
+    ap.add_argument("--spinup-ms", type=float, default=250.0,
+                    help="run the step untimed for this long before the warmup so the clocks have left their idle "
+                         "state (reported as `spinup` in the JSON line; 0 disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=368,
@@ -486,6 +490,13 @@ def main():
         exchange["mode"] = "compact" if cal[0] <= cal[1] else "allreduce"
         exchange["calibration_ms"] = {"compact": round(cal[0], 4), "allreduce": round(cal[1], 4)}
 
+    # Clock spin-up, untimed and before the warmup: the first ~40 ms of work after the device was idle run on
+    # ramping clocks (tools/step_first.py: 1.05 -> 0.90 ms/step over the first 35 steps), and a 5-step warmup ends
+    # inside that ramp.  A training run sees the steady state, so that is what the K timed steps should see too.
+    spin_t0, spin_steps = time.perf_counter(), 0
+    while (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:
+        step(None)
+        spin_steps += 1
     for _ in range(args.warmup):
         step(None)
     events = []
@@ -558,7 +569,8 @@ def main():
             "metric": "fwd+bwd Mpixels/s @1080p, 1M Gaussians, SH3" if args.config == "config3"
                       else f"{'fwd' if forward_only else 'fwd+bwd' + ('+adam' if use_adam else '')} Mpixels/s, {wl.name}",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "spinup": {"ms": args.spinup_ms, "steps": spin_steps, "timed": False},
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.name + (" fwd only" if forward_only else " fwd+bwd") + (" +adam" if use_adam else ""),
                        "n_gaussians": wl.n, "width": wl.width, "height": wl.height, "sh_degree": wl.sh_degree,

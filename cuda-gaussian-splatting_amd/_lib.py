@@ -66,8 +66,12 @@ SIGNATURES = {
                                        C.POINTER(C.c_int64), _P]),
     "cugs_rasterize_forward": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
                                     _P, _P, _P, _P]),
+    "cugs_rasterize_forward_zero": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
+                                         _P, _P, _P, _P, C.c_size_t, _P]),
     "cugs_rasterize_backward": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
+    "cugs_rasterize_backward_prezeroed": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
+                                               _P, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
     "cugs_project_backward": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Camera), _F,
                                    _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cugs_project_backward_adam": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Camera), _F, _P,

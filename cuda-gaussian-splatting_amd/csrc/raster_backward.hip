@@ -264,14 +264,15 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_unpack_grads(int64_t n, const fl
 
 }  // namespace
 
-extern "C" int cugs_rasterize_backward(int width, int height, const float background_host[3],
+namespace {
+int rasterize_backward_impl(int width, int height, const float background_host[3],
                                        const int32_t* tile_ranges, const int32_t* gaussian_indices,
                                        const float* means_2d, const float* cov_2d_inv, const float* rgb,
                                        const float* opacities_act, const float* packed,
                                        const float* dL_dcolor, const float* final_T,
                                        const int32_t* n_contrib, int64_t n, float* grad_accum,
                                        float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
-                                       float* dL_dcov_2d_inv, void* stream) {
+                                       float* dL_dcov_2d_inv, bool prezeroed, void* stream) {
     if (width < 0 || height < 0 || n < 0 || !background_host) return CUGS_EINVAL;
     if (n == 0) return 0;
     if (!grad_accum) return CUGS_EINVAL;
@@ -287,7 +288,8 @@ extern "C" int cugs_rasterize_backward(int width, int height, const float backgr
     const bool stats = cugs_dev_backward_stats();          // the caller allocated n + 1 rows (tools/ablate_backward.py)
     if (stats) rows = n + 1;
 #endif
-    CUGS_RETURN_IF_HIP(hipMemsetAsync(grad_accum, 0, sizeof(float) * CUGS_GRAD_STRIDE * (size_t)rows, st));
+    if (!prezeroed || rows != n)
+        CUGS_RETURN_IF_HIP(hipMemsetAsync(grad_accum, 0, sizeof(float) * CUGS_GRAD_STRIDE * (size_t)rows, st));
 
     const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
     if (ntx > 0 && nty > 0 && gaussian_indices) {               // backward.cu:267-269; NULL indices = no pairs
@@ -324,6 +326,34 @@ extern "C" int cugs_rasterize_backward(int width, int height, const float backgr
         CUGS_LAUNCH_CHECK();
     }
     return 0;
+}
+
+}  // namespace
+
+extern "C" int cugs_rasterize_backward(int width, int height, const float background_host[3],
+                                       const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                                       const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                       const float* opacities_act, const float* packed,
+                                       const float* dL_dcolor, const float* final_T,
+                                       const int32_t* n_contrib, int64_t n, float* grad_accum,
+                                       float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
+                                       float* dL_dcov_2d_inv, void* stream) {
+    return rasterize_backward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
+                                   opacities_act, packed, dL_dcolor, final_T, n_contrib, n, grad_accum, dL_drgb,
+                                   dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv, false, stream);
+}
+
+extern "C" int cugs_rasterize_backward_prezeroed(int width, int height, const float background_host[3],
+                                                 const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                                                 const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                                 const float* opacities_act, const float* packed,
+                                                 const float* dL_dcolor, const float* final_T,
+                                                 const int32_t* n_contrib, int64_t n, float* grad_accum,
+                                                 float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
+                                                 float* dL_dcov_2d_inv, void* stream) {
+    return rasterize_backward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
+                                   opacities_act, packed, dL_dcolor, final_T, n_contrib, n, grad_accum, dL_drgb,
+                                   dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv, true, stream);
 }
 
 #ifdef CUGS_DEV

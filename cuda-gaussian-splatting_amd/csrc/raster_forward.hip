@@ -18,9 +18,19 @@ template <bool PACKED>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, RasterSrc src,
                                                                float* __restrict__ out_color,
                                                                float* __restrict__ out_final_T,
-                                                               int32_t* __restrict__ out_n_contrib) {
+                                                               int32_t* __restrict__ out_n_contrib,
+                                                               float4* __restrict__ zero_buf, uint32_t zero_vec4) {
     __shared__ float4 s_rec[CUGS_BLOCK * CUGS_REC_F4];
     __shared__ int s_wave_done[4];
+
+    // Housekeeping for the backward (cugs_rasterize_forward_zero): this kernel is bound by instruction issue and
+    // leaves HBM nearly idle, so each workgroup clears its slice of the gradient accumulator here - the 64 B/Gaussian
+    // fill that otherwise runs by itself in front of the backward blend.
+    if (zero_buf) {
+        const uint32_t per = (zero_vec4 + gridDim.x - 1) / gridDim.x;
+        const uint32_t lo = blockIdx.x * per, hi = min(zero_vec4, lo + per);
+        for (uint32_t e = lo + threadIdx.x; e < hi; e += CUGS_BLOCK) zero_buf[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
 
     const unsigned tile = cugs_xcd_remap(blockIdx.x, (unsigned)geo.ntiles);
     const int tile_x = (int)(tile % (unsigned)geo.ntx), tile_y = (int)(tile / (unsigned)geo.ntx);
@@ -98,14 +108,20 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
 
 }  // namespace
 
-extern "C" int cugs_rasterize_forward(int width, int height, const float background_host[3],
-                                      const int32_t* tile_ranges, const int32_t* gaussian_indices,
-                                      const float* means_2d, const float* cov_2d_inv, const float* rgb,
-                                      const float* opacities_act, const float* packed, float* out_color,
-                                      float* out_final_T, int32_t* out_n_contrib, void* stream) {
+namespace {
+int rasterize_forward_impl(int width, int height, const float background_host[3], const int32_t* tile_ranges,
+                           const int32_t* gaussian_indices, const float* means_2d, const float* cov_2d_inv,
+                           const float* rgb, const float* opacities_act, const float* packed, float* out_color,
+                           float* out_final_T, int32_t* out_n_contrib, void* zero_buf, size_t zero_bytes, void* stream) {
     if (width < 0 || height < 0 || !background_host) return CUGS_EINVAL;
+    if (zero_bytes && (!zero_buf || (reinterpret_cast<uintptr_t>(zero_buf) & 15u) || (zero_bytes & 15u) ||
+                       zero_bytes / 16 > 0xFFFFFFFFull))
+        return zero_buf ? CUGS_EALIGN : CUGS_EINVAL;
     const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
-    if (ntx == 0 || nty == 0) return 0;                       // forward.cu:204-210: nothing to draw
+    if (ntx == 0 || nty == 0) {                               // forward.cu:204-210: nothing to draw
+        if (zero_bytes) CUGS_RETURN_IF_HIP(hipMemsetAsync(zero_buf, 0, zero_bytes, static_cast<hipStream_t>(stream)));
+        return 0;
+    }
     if (!tile_ranges || !out_color || !out_final_T || !out_n_contrib) return CUGS_EINVAL;
     // gaussian_indices and the per-Gaussian sources may be NULL for an empty pair list (P == 0: every
     // tile range is {0,0} and nothing is dereferenced).  With indices present a source is required.
@@ -115,12 +131,34 @@ extern "C" int cugs_rasterize_forward(int width, int height, const float backgro
     RasterGeom geo{width, height, ntx, ntx * nty, background_host[0], background_host[1], background_host[2]};
     RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    float4* zb = zero_bytes ? static_cast<float4*>(zero_buf) : nullptr;
+    const uint32_t zv = (uint32_t)(zero_bytes / 16);
     if (packed)
         hipLaunchKernelGGL((k_raster_forward<true>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src,
-                           out_color, out_final_T, out_n_contrib);
+                           out_color, out_final_T, out_n_contrib, zb, zv);
     else
         hipLaunchKernelGGL((k_raster_forward<false>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src,
-                           out_color, out_final_T, out_n_contrib);
+                           out_color, out_final_T, out_n_contrib, zb, zv);
     CUGS_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace
+
+extern "C" int cugs_rasterize_forward(int width, int height, const float background_host[3],
+                                      const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                                      const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                      const float* opacities_act, const float* packed, float* out_color,
+                                      float* out_final_T, int32_t* out_n_contrib, void* stream) {
+    return rasterize_forward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
+                                  opacities_act, packed, out_color, out_final_T, out_n_contrib, nullptr, 0, stream);
+}
+
+extern "C" int cugs_rasterize_forward_zero(int width, int height, const float background_host[3],
+                                           const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                                           const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                           const float* opacities_act, const float* packed, float* out_color,
+                                           float* out_final_T, int32_t* out_n_contrib, void* zero_buf,
+                                           size_t zero_bytes, void* stream) {
+    return rasterize_forward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
+                                  opacities_act, packed, out_color, out_final_T, out_n_contrib, zero_buf, zero_bytes, stream);
 }

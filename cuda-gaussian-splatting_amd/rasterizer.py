@@ -253,7 +253,9 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
 def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: torch.Tensor,
                       opacities: torch.Tensor, tile_ranges: torch.Tensor, gaussian_indices: torch.Tensor,
                       img_w: int, img_h: int, background: Sequence[float],
-                      packed: Optional[torch.Tensor] = None) -> ForwardOutput:
+                      packed: Optional[torch.Tensor] = None, zero_buf: Optional[torch.Tensor] = None) -> ForwardOutput:
+    """`zero_buf` (optional, not in the reference): a contiguous float32 tensor the launch also fills with zeros -
+    the accumulator of the backward blend, cleared for free by this issue-bound kernel (cugs_rasterize_forward_zero)."""
     _torch_check(means_2d.is_cuda, "means_2d must be on CUDA")
     dev = means_2d.device
     color = torch.empty((img_h, img_w, 3), dtype=torch.float32, device=dev)
@@ -262,6 +264,16 @@ def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: tor
     if img_w == 0 or img_h == 0:
         return ForwardOutput(color, final_T, n_contrib)
     bg = (C.c_float * 3)(*[float(b) for b in background])
+    if zero_buf is not None:
+        _torch_check(zero_buf.is_contiguous() and zero_buf.dtype == torch.float32 and zero_buf.numel() % 4 == 0,
+                     "zero_buf must be a contiguous float32 tensor of a multiple of four elements")
+        check(lib.cugs_rasterize_forward_zero(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
+                                              _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
+                                              _ptr(cov_2d_inv.contiguous()), _ptr(rgb.contiguous()),
+                                              _ptr(opacities.contiguous()), _ptr(packed), _ptr(color), _ptr(final_T),
+                                              _ptr(n_contrib), _ptr(zero_buf), zero_buf.numel() * 4, _stream(dev)),
+              "cugs_rasterize_forward_zero")
+        return ForwardOutput(color, final_T, n_contrib)
     check(lib.cugs_rasterize_forward(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
                                      _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
                                      _ptr(cov_2d_inv.contiguous()), _ptr(rgb.contiguous()),
@@ -274,12 +286,19 @@ def rasterize_backward(dL_dcolor: torch.Tensor, means_2d: torch.Tensor, cov_2d_i
                        rgb: torch.Tensor, opacities: torch.Tensor, tile_ranges: torch.Tensor,
                        gaussian_indices: torch.Tensor, final_T: torch.Tensor, n_contrib: torch.Tensor,
                        img_w: int, img_h: int, background: Sequence[float], n_gaussians: int,
-                       packed: Optional[torch.Tensor] = None, unpack: bool = True) -> RasterizeBackwardOutput:
+                       packed: Optional[torch.Tensor] = None, unpack: bool = True,
+                       zeroed_accum: Optional[torch.Tensor] = None) -> RasterizeBackwardOutput:
+    """`zeroed_accum` (optional, not in the reference): an [N, 16] accumulator that is already all zeros (cleared by
+    rasterize_forward(..., zero_buf=...)): used as is, without the fill."""
     _torch_check(dL_dcolor.is_cuda, "dL_dcolor must be on CUDA")
     dev = dL_dcolor.device
     n = int(n_gaussians)
     f = dict(dtype=torch.float32, device=dev)
-    accum = torch.empty((n, _lib.GRAD_STRIDE), **f)
+    if zeroed_accum is not None:
+        _torch_check(tuple(zeroed_accum.shape) == (n, _lib.GRAD_STRIDE) and zeroed_accum.is_contiguous(),
+                     "zeroed_accum must be a contiguous [N, 16] float32 tensor")
+    accum = zeroed_accum if zeroed_accum is not None else torch.empty((n, _lib.GRAD_STRIDE), **f)
+    entry = lib.cugs_rasterize_backward_prezeroed if zeroed_accum is not None else lib.cugs_rasterize_backward
     if unpack:
         d_rgb, d_opa = torch.empty((n, 3), **f), torch.empty((n,), **f)
         d_means, d_cov = torch.empty((n, 2), **f), torch.empty((n, 3), **f)
@@ -287,7 +306,7 @@ def rasterize_backward(dL_dcolor: torch.Tensor, means_2d: torch.Tensor, cov_2d_i
         d_rgb = d_opa = d_means = d_cov = None
     if n > 0:
         bg = (C.c_float * 3)(*[float(b) for b in background])
-        check(lib.cugs_rasterize_backward(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
+        check(entry(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
                                           _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
                                           _ptr(cov_2d_inv.contiguous()), _ptr(rgb.contiguous()),
                                           _ptr(opacities.contiguous()), _ptr(packed),
@@ -362,7 +381,8 @@ def sh_backward_views(degree: int, positions: torch.Tensor, gated_rgb_views: tor
 # --------------------------------------------------------------------------------------
 # render / render_backward (rasterizer.cpp:22-186)
 # --------------------------------------------------------------------------------------
-def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings) -> RenderOutput:
+def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, for_backward: bool = True) -> RenderOutput:
+    """`for_backward=False` (evaluation, viewer): skips preparing the backward's accumulator (64 B/Gaussian)."""
     _torch_check(model.is_valid(), "GaussianModel is not valid")
     _torch_check(model.positions.is_cuda, "GaussianModel must be on CUDA device")
     n = model.num_gaussians()
@@ -381,9 +401,11 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings) -
     active_degree = min(int(settings.active_sh_degree), model.max_sh_degree())
     proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs,
                              camera, active_degree, settings.scale_modifier)
+    # the backward blend's accumulator, cleared in passing by the forward blend (which leaves HBM idle)
+    accum = torch.empty((n, _lib.GRAD_STRIDE), **f) if for_backward else None
     blend = lambda s: rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
                                         s.gaussian_values_sorted, camera.width, camera.height, settings.background,
-                                        packed=proj.packed)
+                                        packed=proj.packed, zero_buf=accum)
     srt = sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, camera.width,
                                    camera.height, want_keys=False)
     fwd = blend(srt)                                     # queued behind the sort; the host has not waited yet
@@ -393,7 +415,7 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings) -
             fwd = blend(srt)
     return RenderOutput(fwd.color, fwd.final_T, fwd.n_contrib, proj.means_2d, proj.depths, proj.cov_2d_inv,
                         proj.radii, proj.rgb, proj.opacities_act, srt.gaussian_values_sorted, srt.tile_ranges,
-                        packed=proj.packed, total_pairs=srt.total_pairs)
+                        packed=proj.packed, total_pairs=srt.total_pairs, zeroed_accum=accum)
 
 
 def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: GaussianModel,
@@ -417,10 +439,12 @@ def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: Ga
                               torch.zeros((0, 1), **f), torch.zeros_like(model.sh_coeffs),
                               torch.zeros((0, 2), **f))
     active_degree = min(int(settings.active_sh_degree), model.max_sh_degree())
+    # the accumulator render() had the forward blend clear is good for ONE backward
+    zeroed, render_out.zeroed_accum = getattr(render_out, "zeroed_accum", None), None
     rb = rasterize_backward(dL_dcolor, render_out.means_2d, render_out.cov_2d_inv, render_out.rgb,
                             render_out.opacities_act, render_out.tile_ranges, render_out.gaussian_indices,
                             render_out.final_T, render_out.n_contrib, camera.width, camera.height,
-                            settings.background, n, packed=render_out.packed, unpack=False)
+                            settings.background, n, packed=render_out.packed, unpack=False, zeroed_accum=zeroed)
     d_means_2d = torch.empty((n, 2), **f)
     if fused_adam is not None:
         _torch_check(fused_adam.model_ is model, "fused_adam must have been built on this model")

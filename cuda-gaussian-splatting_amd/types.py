@@ -186,6 +186,7 @@ class RenderOutput:
     tile_ranges: torch.Tensor
     packed: Optional[torch.Tensor] = None       # scratch kept alive for render_backward
     total_pairs: int = 0
+    zeroed_accum: Optional[torch.Tensor] = None # [N,16] accumulator already cleared by the forward blend (one backward)
 
 
 @dataclass

@@ -132,6 +132,17 @@ int cugs_rasterize_forward(int width, int height, const float background_host[3]
                            float* out_color, float* out_final_T, int32_t* out_n_contrib,
                            void* stream);
 
+/* The same blend, and in passing a zero-fill of `zero_buf` (zero_bytes: multiple of 16, buffer 16-byte aligned): the
+ * blend kernel is bound by instruction issue and leaves HBM idle, so the [n, CUGS_GRAD_STRIDE] accumulator the
+ * backward needs is cleared here for free instead of by a fill in front of cugs_rasterize_backward
+ * (then call cugs_rasterize_backward_prezeroed). */
+int cugs_rasterize_forward_zero(int width, int height, const float background_host[3],
+                                const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                                const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                const float* opacities_act, const float* packed,
+                                float* out_color, float* out_final_T, int32_t* out_n_contrib,
+                                void* zero_buf, size_t zero_bytes, void* stream);
+
 /* ---- a7: rasterize_backward (backward.cu:239-306, kernel :31-233) -------------------
  * grad_accum: [n,CUGS_GRAD_STRIDE] floats, 64-byte aligned scratch (zeroed by the callee);
  * row = {dL_drgb[3], dL_dopacity_act, dL_dmeans_2d[2], dL_dcov_2d_inv[3], 0...}.
@@ -145,6 +156,17 @@ int cugs_rasterize_backward(int width, int height, const float background_host[3
                             const int32_t* n_contrib, int64_t n, float* grad_accum,
                             float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
                             float* dL_dcov_2d_inv, void* stream);
+
+/* cugs_rasterize_backward for a grad_accum that is ALREADY all zeros (cleared by cugs_rasterize_forward_zero since
+ * its last use): skips the fill.  Everything else as above. */
+int cugs_rasterize_backward_prezeroed(int width, int height, const float background_host[3],
+                                      const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                                      const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                      const float* opacities_act, const float* packed,
+                                      const float* dL_dcolor, const float* final_T,
+                                      const int32_t* n_contrib, int64_t n, float* grad_accum,
+                                      float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
+                                      float* dL_dcov_2d_inv, void* stream);
 
 /* ---- a8+a9: project_backward (projection_backward.cu:253-344, kernel :26-247) -------
  * One launch: k_project_backward + directions + k_evaluate_sh_backward.  The incoming 2-D

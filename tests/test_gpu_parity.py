@@ -530,3 +530,45 @@ def test_backward_with_clamped_alphas_and_tiny_images(pkg, orc, dev):
         for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs", "dL_dmeans_2d"):
             got = np_(getattr(grads, name)).reshape(refb[name].shape)
             assert max_err_over_max(got, refb[name]) <= GRAD_TOL, (n, name)
+
+
+def test_forward_blend_clears_the_backward_accumulator(pkg, orc, dev):
+    """cugs_rasterize_forward_zero / cugs_rasterize_backward_prezeroed: the forward blend fills a DIRTY buffer with
+    zeros while it renders (image bit-equal to the plain entry), the backward run on that buffer without its own
+    fill gives the gradients of the filling path (<= 1e-5: atomics reorder sums), an odd-sized buffer is covered to
+    its last 16 bytes, a misaligned one is refused, and a RenderOutput hands its cleared accumulator out ONCE - a
+    second render_backward on the same output falls back to the filling path and is still right."""
+    n, w, h, deg = 20000, 333, 217, 2
+    arrays, cam = _scene(pkg, n, w, h, deg, seed=77, mu_s=-3.8)
+    settings = pkg.RenderSettings(background=[0.3, 0.6, 0.1], active_sh_degree=deg)
+    model = pkg.scene.to_model(arrays, dev)
+    g = torch.from_numpy(pkg.scene.make_dl_dcolor(w, h, seed=78)).to(dev)
+    R = pkg.rasterizer
+    out = pkg.render(model, cam, settings)
+    assert out.zeroed_accum is not None and int(torch.count_nonzero(out.zeroed_accum)) == 0
+    args = (out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges, out.gaussian_indices,
+            w, h, settings.background)
+    plain = R.rasterize_forward(*args, packed=out.packed)
+    for numel in (4, 16 * n, 16 * n + 4, 1 << 22):             # smaller than the grid, exact, odd tail, large
+        dirty = torch.full((numel + 4,), 7.0, device=dev)
+        z = R.rasterize_forward(*args, packed=out.packed, zero_buf=dirty[:numel])
+        assert torch.equal(z.color, plain.color) and torch.equal(z.n_contrib, plain.n_contrib)
+        assert int(torch.count_nonzero(dirty[:numel])) == 0 and bool((dirty[numel:] == 7.0).all())
+    with pytest.raises(RuntimeError):
+        R.rasterize_forward(*args, packed=out.packed, zero_buf=torch.zeros(9, device=dev)[1:])     # misaligned
+    bargs = (g, out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges, out.gaussian_indices,
+             out.final_T, out.n_contrib, w, h, settings.background, n)
+    filled = R.rasterize_backward(*bargs, packed=out.packed)
+    pre = R.rasterize_backward(*bargs, packed=out.packed, zeroed_accum=out.zeroed_accum)
+    for k in ("dL_drgb", "dL_dopacity_act", "dL_dmeans_2d", "dL_dcov_2d_inv"):
+        a, b = getattr(filled, k), getattr(pre, k)
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), k
+    # through render()/render_backward(): consumed once, then the filling path
+    out2 = pkg.render(model, cam, settings)
+    first = pkg.render_backward(g, out2, model, cam, settings)
+    assert out2.zeroed_accum is None
+    second = pkg.render_backward(g, out2, model, cam, settings)
+    for k in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs"):
+        a, b = getattr(first, k), getattr(second, k)
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), k
+    assert pkg.render(model, cam, settings, for_backward=False).zeroed_accum is None
