@@ -13,6 +13,11 @@
 // 8 B x N x 4 passes, (3) moves 8 B x P x ceil(log2(tiles)/8) passes (2 at 1080p) instead of
 // 12 B x P x 8 passes.  Every pass is the same three kernels: per-workgroup digit histogram,
 // per-digit row scan, stable scatter with wave64 ballot ranking.  All HBM-bound integer work.
+//
+// Views with many pairs per Gaussian (>= 13: dense scenes, close-ups), on images of up to 256 x 256 tiles, save
+// the first of the pair-level passes: the pairs are EMITTED already ordered by tile column (k_col_emit) - which
+// needs a histogram and a ranking per (Gaussian, column) instead of per pair - and one stable pass by tile row
+// finishes (3).  Both routes give the same permutation (tests/test_gpu_parity.py runs each against the oracle).
 #include "cugs_gaussian_math.h"
 
 #include <atomic>
@@ -28,6 +33,12 @@ constexpr int CHUNK_MIN = CUGS_BLOCK * IPT;       // 4096 items per workgroup: d
 #endif
 constexpr int CHUNK_PAIR = CUGS_PAIR_CHUNK_MULT * CHUNK_MIN;   // pair-level passes (8192 / 16384: 4 % / 30 % slower, profiles/README.md)
 constexpr int FILL_CHUNK = CUGS_BLOCK;            // Gaussians per workgroup in scan/fill (one per thread)
+#ifndef CUGS_COL_WAVES
+#define CUGS_COL_WAVES 16
+#endif
+constexpr int COL_WAVES = CUGS_COL_WAVES;         // waves per workgroup of the column-ordered emission: the longer a
+constexpr int COL_CHUNK = COL_WAVES * CUGS_WAVE;  // workgroup's run in each tile column, the fewer partial lines it writes
+static_assert(COL_CHUNK % FILL_CHUNK == 0, "whole FILL_CHUNK blocks per column workgroup");
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline uint32_t nblocks_for(int64_t count, int chunk) { return (uint32_t)((count + chunk - 1) / chunk); }
@@ -43,6 +54,8 @@ struct SortWsN {
     uint32_t* tot;               // [RADIX]
     uint32_t* blocksum;          // per FILL_CHUNK block pair counts   [nfill + 2]
     uint32_t* hist;              // [RADIX][nblk_n] digit-major
+    uint32_t* colhist;           // [RADIX][ncol] pairs per (tile column, COL_CHUNK block), as counted
+    uint32_t* colscan;           // ... and scanned along each column's row
     size_t bytes;
 };
 struct SortWsP {
@@ -71,6 +84,8 @@ SortWsN carve_n(void* base, int64_t n) {
     w.tot = c.take<uint32_t>(RADIX);
     w.blocksum = c.take<uint32_t>((size_t)nblocks_for(n, FILL_CHUNK) + 2);
     w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, CHUNK_MIN) + 1));
+    w.colhist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
+    w.colscan = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
     w.bytes = c.off;
     return w;
 }
@@ -209,12 +224,13 @@ __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, u
     if (threadIdx.x < RADIX) hist[threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
 }
 
-// Block d: exclusive scan of row d of hist (in place); tot[d] = row sum.
-__global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(uint32_t* __restrict__ hist,
+// Block d: exclusive scan of row d of hist into `out` (may be hist itself); tot[d] = row sum.
+__global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(const uint32_t* hist, uint32_t* out,
                                                                 uint32_t nblk, uint32_t* __restrict__ tot) {
     __shared__ uint32_t s_tmp[4];
     constexpr int PER = 8;                                   // consecutive entries per thread: 2048 per iteration
-    uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+    const uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+    uint32_t* orow = out + (size_t)blockIdx.x * nblk;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nblk; base += CUGS_BLOCK * PER) {
         const uint32_t i0 = base + threadIdx.x * PER;
@@ -225,7 +241,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(uint32_t* __rest
         uint32_t run = carry + block_exclusive_scan(sum, s_tmp, &total);
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            if (i0 + e < nblk) row[i0 + e] = run;
+            if (i0 + e < nblk) orow[i0 + e] = run;
             run += v[e];
         }
         carry += total;
@@ -353,6 +369,45 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
 // ------------------------------------------------------------------------------------
 // Pair emission in depth order
 // ------------------------------------------------------------------------------------
+// k_fill_blocksums for the column-ordered emission, COL_CHUNK Gaussians per workgroup: the same gather and block
+// sums (one per FILL_CHUNK Gaussians), and the pairs of the workgroup per tile column (colhist[column][workgroup],
+// digit-major like the radix histograms): a Gaussian adds its rectangle height to each column it covers; slots the
+// reference leaves at zero (quirk Q12) count for column 0, where their (tile 0, Gaussian 0) pairs go.
+__global__ __launch_bounds__(COL_CHUNK) void k_fill_blocksums_cols(uint32_t n, const uint32_t* __restrict__ order,
+                                                                   const int4* __restrict__ rect,
+                                                                   int4* __restrict__ rect_sorted,
+                                                                   uint32_t* __restrict__ blocksum, uint32_t nfill,
+                                                                   uint32_t* __restrict__ colhist, uint32_t ncol) {
+    __shared__ uint32_t s_wsum[COL_WAVES];
+    __shared__ uint32_t s_col[RADIX];
+    const uint32_t tid = threadIdx.x;
+    if (tid < RADIX) s_col[tid] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * COL_CHUNK + tid;
+    uint32_t acc = 0u;
+    int w = 0, h = 0, x0 = 0;
+    if (i < n) {
+        const int4 r = rect[order[i]];             // the one gather per Gaussian
+        rect_sorted[i] = r;
+        acc = (uint32_t)r.w;
+        w = r.z & 0xFFFF; h = r.z >> 16; x0 = r.x;
+        if ((uint32_t)(w * h) < acc) atomicAdd(&s_col[0], acc - (uint32_t)(w * h));
+    }
+    for (int c = 0; c < w; ++c) atomicAdd(&s_col[x0 + c], (uint32_t)h);
+    const uint32_t inc = wave_inclusive_scan(acc);
+    if ((tid & 63u) == 63u) s_wsum[tid >> 6] = inc;
+    __syncthreads();
+    constexpr int WPF = FILL_CHUNK / CUGS_WAVE;    // waves per FILL_CHUNK block
+    if (tid < COL_WAVES / WPF) {
+        const uint32_t fb = blockIdx.x * (COL_WAVES / WPF) + tid;
+        uint32_t sum = 0u;
+#pragma unroll
+        for (int v = 0; v < WPF; ++v) sum += s_wsum[tid * WPF + v];
+        if (fb < nfill) blocksum[fb] = sum;
+    }
+    if (tid < RADIX) colhist[(size_t)tid * ncol + blockIdx.x] = s_col[tid];
+}
+
 __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_blocksums(uint32_t n,
                                                                const uint32_t* __restrict__ order,
                                                                const int4* __restrict__ rect,
@@ -496,12 +551,203 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     }
 }
 
+// Pair emission ordered by TILE COLUMN (then depth, then row): the first pass of the stable sort by tile id,
+// done while the pairs are generated.  Key written per pair: (row << 8 | column), images of <= 256 x 256 tiles.
+// The unit is an ITEM = (Gaussian, column it covers), worth `height` consecutive pairs - ~3x fewer items than
+// pairs at 1080p.  A workgroup takes COL_CHUNK Gaussians of the depth order and
+//   (b) sets, per column, one bit per Gaussian that covers it (LDS bit matrix; OR commutes, so no ordering issue);
+//   (c) counts each column's bits (prefix per 32-Gaussian word) and scans the counts over the columns;
+//   (d) drops each item's record at  column start + set bits below its Gaussian  - the items are now sorted by
+//       (column, depth) - with its height beside it;
+//   (e) scans the heights: the local slot of every item's first pair, and per column the offset between local
+//       slots and the column's run in the output (column start + pairs of the workgroups before this one, from
+//       the scanned column histogram of k_fill_blocksums_cols);
+//   (g) streams the pairs out, 64 sorted items per wave round (rounds handed out by an LDS counter), lane = item:
+//       neighbouring lanes own neighbouring runs of the output, so the `height` store instructions of a round
+//       complete each other's cache lines (writing from UNSORTED items cost 2x the HBM write requests; a slot-
+//       parallel loop with a 6-step owner search per slot was bound by its ~136 instructions per 64 pairs).
+// LDS holds ICAP items; a workgroup with more (dense views) works in batches of whole Gaussians.
+// Slots the reference's loops leave at zero (tiles_touched beyond the w x h pairs of the rectangle: the Q12
+// Gaussians, whose rectangle is empty) are ONE more item of the Gaussian worth that many (tile 0, Gaussian 0)
+// pairs, in a pseudo column ordered before column 0 and sharing its run.  Q12 Gaussians are first in depth
+// order, hence first in column 0, hence (row pass) first in tile 0, where the reference's zero pairs sort to.
+#ifdef CUGS_DEV
+__device__ unsigned long long g_emit_prof[16];     // development build: 100 MHz ticks per phase of k_col_emit, summed over workgroups
+#define EMIT_TICK(slot) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+        atomicAdd(&g_emit_prof[slot], now_ - tick_); tick_ = now_; } } while (0)
+#else
+#define EMIT_TICK(slot) do { } while (0)
+#endif
+__global__ __launch_bounds__(COL_CHUNK) void k_col_emit(
+    uint32_t n, uint32_t pairs_or_cap, const unsigned long long* __restrict__ dev_count,
+    const uint32_t* __restrict__ order, const int4* __restrict__ rect_sorted,
+    const uint32_t* __restrict__ colscan, const uint32_t* __restrict__ coltot, uint32_t nblk,
+    uint16_t* __restrict__ ptile, uint32_t* __restrict__ pidx,
+    uint32_t* __restrict__ zero_pairs, int32_t* __restrict__ tile_ranges, uint32_t range_dwords) {
+    constexpr int NT = COL_CHUNK, NW = COL_WAVES;
+    constexpr int NWORD = NT / 32;                                   // bit-matrix words per column
+    constexpr int NC = RADIX + 1, ZCOL = RADIX;                      // tile columns + the zero-slot pseudo column
+    constexpr int NCP = RADIX + 4;
+    constexpr int PER = 6;                                           // staged items per thread
+    constexpr int ICAP = PER * NT;
+    constexpr int IWIN = ICAP - (RADIX + 1);                         // a batch: the Gaussians whose first item is in one window
+    static_assert(NT >= NC, "one thread per column");
+    __shared__ uint32_t s_cover[NWORD][NCP];
+    __shared__ uint16_t s_wpre[NWORD][NCP];
+    __shared__ uint32_t s_istart[NCP];                               // first sorted item of each column (this batch)
+    __shared__ uint32_t s_gpos[NCP];                                 // where the workgroup's next pair of each column goes
+    __shared__ uint32_t s_delta[NCP];                                // output position - local slot, per column (this batch)
+    __shared__ uint2 s_item[ICAP];                                   // {row0 << 8 | column (bit 31: zero item), Gaussian}
+    __shared__ uint32_t s_poff[ICAP + 1];                            // height, then local slot of the item's first pair
+    __shared__ uint32_t s_tmp[NW];
+    __shared__ uint32_t s_next;
+#ifdef CUGS_DEV
+    unsigned long long tick_ = __builtin_readcyclecounter();
+#endif
+    const uint32_t total_pairs = live_count(pairs_or_cap, dev_count);
+    for (uint32_t z = blockIdx.x * NT + threadIdx.x; z < range_dwords; z += gridDim.x * NT) tile_ranges[z] = 0;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t i = blockIdx.x * NT + tid;
+    uint32_t g = 0, t = 0;
+    int x0 = 0, y0 = 0, w = 0, h = 0;
+    if (i < n) {
+        g = order[i];
+        const int4 r = rect_sorted[i];
+        t = (uint32_t)r.w;
+        x0 = r.x; y0 = r.y; w = r.z & 0xFFFF; h = r.z >> 16;
+    }
+    const uint32_t nzero = (uint32_t)(w * h) < t ? t - (uint32_t)(w * h) : 0u;
+    if (nzero) atomicAdd(zero_pairs, nzero);                         // quirk Q12 slots (rare)
+    const uint32_t ni = t == 0u ? 0u : (uint32_t)w + (nzero ? 1u : 0u);   // items of this Gaussian
+    {   // where this workgroup's run of each column starts
+        const bool col = tid < RADIX;
+        const uint32_t col_start = block_exclusive_scan<NW>(col ? coltot[tid] : 0u, s_tmp, nullptr);
+        if (col) s_gpos[tid] = col_start + colscan[(size_t)tid * nblk + blockIdx.x];
+    }
+    uint32_t itot;
+    const uint32_t ioff = block_exclusive_scan<NW>(ni, s_tmp, &itot);
+    const uint32_t my_batch = ioff / IWIN;
+    const uint32_t nbatch = (itot + IWIN - 1) / IWIN;
+    const uint32_t word = tid >> 5, bit = 1u << (tid & 31u);
+    const uint32_t cu = tid == 0 ? (uint32_t)ZCOL : tid - 1u;        // column of thread `tid` in scan order: pseudo column first
+    EMIT_TICK(0);
+
+    for (uint32_t k = 0; k < nbatch; ++k) {
+        const bool mine = t > 0u && my_batch == k;
+        for (uint32_t e = tid; e < NWORD * NCP; e += NT) (&s_cover[0][0])[e] = 0u;
+        __syncthreads();
+        if (mine) {                                                  // (b)
+            for (int c = 0; c < w; ++c) atomicOr(&s_cover[word][x0 + c], bit);
+            if (nzero) atomicOr(&s_cover[word][ZCOL], bit);
+        }
+        __syncthreads();
+        EMIT_TICK(1);
+        uint32_t cnt = 0u;                                           // (c)
+        if (tid < NC) {
+            uint32_t bits[NWORD];
+#pragma unroll
+            for (int q = 0; q < NWORD; ++q) bits[q] = s_cover[q][cu];
+#pragma unroll
+            for (int q = 0; q < NWORD; ++q) {
+                s_wpre[q][cu] = (uint16_t)cnt;
+                cnt += __popc(bits[q]);
+            }
+        }
+        uint32_t icount;
+        const uint32_t ist = block_exclusive_scan<NW>(cnt, s_tmp, &icount);
+        if (tid < NC) s_istart[cu] = ist;
+        __syncthreads();
+        EMIT_TICK(2);
+        if (mine) {                                                  // (d)
+            for (int c = 0; c < w; ++c) {
+                const uint32_t col = (uint32_t)(x0 + c);
+                const uint32_t at = s_istart[col] + s_wpre[word][col] + __popc(s_cover[word][col] & (bit - 1u));
+                s_item[at] = make_uint2(((uint32_t)y0 << 8) | col, g);
+                s_poff[at] = (uint32_t)h;
+            }
+            if (nzero) {
+                const uint32_t at = s_istart[ZCOL] + s_wpre[word][ZCOL] + __popc(s_cover[word][ZCOL] & (bit - 1u));
+                s_item[at] = make_uint2(0x80000000u, 0u);
+                s_poff[at] = nzero;
+            }
+        }
+        __syncthreads();
+        EMIT_TICK(3);
+        {                                                            // (e) heights -> local slots; s_poff[icount] = pairs of the batch
+            const uint32_t e0 = tid * PER;
+            uint32_t v[PER], sum = 0u;
+#pragma unroll
+            for (int e = 0; e < PER; ++e) { v[e] = (e0 + e < icount) ? s_poff[e0 + e] : 0u; sum += v[e]; }
+            uint32_t run = block_exclusive_scan<NW>(sum, s_tmp, nullptr);
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                if (e0 + e <= icount) s_poff[e0 + e] = run;
+                run += v[e];
+            }
+        }
+        __syncthreads();
+        if (tid >= 1u && tid < NC) {                                 // column cu = tid - 1; column 0 also serves the pseudo column
+            const uint32_t first = (cu == 0u) ? s_istart[ZCOL] : ist;          // the pseudo column's items sit right before column 0's
+            const uint32_t lo_slot = s_poff[first], hi_slot = s_poff[ist + cnt];
+            const uint32_t d = s_gpos[cu] - lo_slot;
+            s_delta[cu] = d;
+            if (cu == 0u) s_delta[ZCOL] = d;
+            s_gpos[cu] += hi_slot - lo_slot;
+        }
+        if (tid == 0) s_next = 0u;
+        __syncthreads();
+        EMIT_TICK(4);
+        const uint32_t nround = (icount + CUGS_WAVE - 1) / CUGS_WAVE;  // (g)
+        while (true) {
+            uint32_t r = 0u;
+            if (lane == 0) r = atomicAdd(&s_next, 1u);
+            r = __builtin_amdgcn_readfirstlane(r);
+            if (r >= nround) break;
+            const uint32_t it = r * CUGS_WAVE + lane;
+            const bool valid = it < icount;
+            uint32_t slot = 0u, cnt_it = 0u;
+            uint2 rec = make_uint2(0u, 0u);
+            if (valid) {
+                slot = s_poff[it];
+                cnt_it = s_poff[it + 1] - slot;
+                rec = s_item[it];
+            }
+            const bool zero = rec.x >> 31;
+            const uint32_t dst0 = slot + s_delta[zero ? (uint32_t)ZCOL : (rec.x & 255u)];
+            // lane = item, walking down its rows: neighbouring lanes hold neighbouring runs of the output, so the
+            // `height` store instructions of a round fill the same cache lines between them
+            if (!zero) {
+                const uint32_t room = dst0 < total_pairs ? total_pairs - dst0 : 0u;     // never write past the buffers
+                const uint32_t rows = min(cnt_it, room);
+                uint16_t* kp = ptile + dst0;
+                uint32_t* ip = pidx + dst0;
+                uint32_t key = rec.x;
+                for (uint32_t y = 0; y < rows; ++y) {
+                    kp[y] = (uint16_t)key;
+                    ip[y] = rec.y;
+                    key += 256u;
+                }
+            }
+            for (unsigned long long m = __ballot(valid && zero); m; m &= m - 1ull) {   // zero slots: by the whole wave
+                const int l = __builtin_ctzll(m);
+                const uint32_t p = __shfl(dst0, l), c = __shfl(cnt_it, l);
+                for (uint32_t sl = lane; sl < c; sl += CUGS_WAVE)
+                    if (p + sl < total_pairs) { ptile[p + sl] = 0; pidx[p + sl] = 0u; }
+            }
+        }
+        EMIT_TICK(5);
+        __syncthreads();
+        EMIT_TICK(6);
+    }
+}
+
 // k_compute_tile_ranges (sorting.cu:82-109) on the sorted tile ids; optionally rebuilds the
 // reference's sorted 64-bit keys (SortingOutput::gaussian_keys_sorted, sorting.hpp:20).
-template <typename K>
+// COLKEY: the keys are (row << 8 | column) as written by k_col_emit; ntx turns them back into tile ids.
+template <typename K, bool COLKEY>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t pairs_or_cap,
                                                             const unsigned long long* __restrict__ dev_count,
-                                                            const K* __restrict__ ptile,
+                                                            const K* __restrict__ ptile, uint32_t ntx,
                                                             const int32_t* __restrict__ pidx,
                                                             const float* __restrict__ depths,
                                                             int32_t* __restrict__ tile_ranges,
@@ -527,6 +773,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t pairs_or_ca
         for (int e = 0; e < PER; ++e) t[e] = (i0 + e < total_pairs) ? (uint32_t)ptile[i0 + e] : 0u;
     }
     uint32_t prev = (i0 == 0) ? 0u : (uint32_t)ptile[i0 - 1];
+    if constexpr (COLKEY) {
+        prev = (prev >> 8) * ntx + (prev & 255u);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) t[e] = (t[e] >> 8) * ntx + (t[e] & 255u);
+    }
     const uint32_t nzero = keys_sorted ? *zero_pairs : 0u;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -608,7 +859,7 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
                            (1u << bits) - 1u, hist, nblk, ctl);
         CUGS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, hist, nblk, tot);
+    hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, hist, hist, nblk, tot);
     CUGS_LAUNCH_CHECK();
 #ifdef CUGS_DEV
     if (rank_mode() == 1) {               // digit width only matters to the ballot ranking: one instantiation
@@ -636,6 +887,20 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
     return 0;
 }
 
+// Column-ordered pair emission: (row << 8 | column) must fit the 16-bit key.  Measured on MI355X, 1 M Gaussians at
+// 1080p, whole sort (tools/sort_routes.py): 8.4 pairs per Gaussian 0.249 ms against 0.218 ms for emission in depth
+// order + two radix passes; 14.8: 0.273 / 0.294; 23.5: 0.331 / 0.423; 45.2: 0.513 / 0.706 - it costs more per
+// Gaussian and 7 instead of 13 us per million pairs, and pays from ~13 pairs per Gaussian (dense views, close-ups).
+inline bool column_path(int ntx, int nty) { return ntx <= 256 && nty <= 256; }
+#ifdef CUGS_DEV
+std::atomic<int> g_col_min_ratio{13};             // development build: movable, to measure both routes on one view
+inline bool column_path_pays(uint32_t n, uint32_t pairs) {
+    return (unsigned long long)pairs >= (unsigned long long)g_col_min_ratio.load(std::memory_order_relaxed) * n;
+}
+#else
+inline bool column_path_pays(uint32_t n, uint32_t pairs) { return (unsigned long long)pairs >= 13ull * n; }
+#endif
+
 int tile_bits(int tiles) {
     int b = 1;
     while ((1 << b) < tiles) ++b;
@@ -658,6 +923,24 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
     K* tk[2] = {static_cast<K*>(wp.ptile[0]), static_cast<K*>(wp.ptile[1])};
     uint32_t* tv[2] = {wp.pidx[0], wp.pidx[1]};
     uint32_t* vals_final = reinterpret_cast<uint32_t*>(values_sorted);
+    if constexpr (sizeof(K) == 2) {
+        if (column_path(ntx, nty) && column_path_pays(un, up)) {
+            // pairs emitted in tile-column order (row << 8 | column keys), then ONE stable pass by row
+            const uint32_t ncol = nblocks_for(un, COL_CHUNK);
+            hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, ws.colhist, ws.colscan, ncol, ws.tot);
+            CUGS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_col_emit, dim3(ncol), dim3(COL_CHUNK), 0, st, un, up, dev_count, order, ws.rect[1],
+                               ws.colscan, ws.tot, ncol, tk[0], tv[0], ctl, tile_ranges, (uint32_t)(2 * tiles));
+            CUGS_LAUNCH_CHECK();
+            int rc = radix_pass<K, false, 512, CHUNK_PAIR>(tk[0], tv[0], up, dev_count, 8, tile_bits(nty), wp.hist, ws.tot,
+                                                           tk[1], vals_final, false, ctl, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_tile_ranges<K, true>), dim3(nblocks_for(up, CUGS_BLOCK * 8)), dim3(CUGS_BLOCK), 0, st, up,
+                               dev_count, tk[1], (uint32_t)ntx, values_sorted, depths, tile_ranges, keys_sorted, ctl + 1);
+            CUGS_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((k_fill_pairs<K>), dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, up, dev_count, order, ws.rect[1], ntx,
                        ws.blocksum, tk[0], tv[0], ctl, tile_ranges, (uint32_t)(2 * tiles));
     CUGS_LAUNCH_CHECK();
@@ -671,8 +954,8 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         if (rc) return rc;
         cur ^= 1;
     }
-    hipLaunchKernelGGL((k_tile_ranges<K>), dim3(nblocks_for(up, CUGS_BLOCK * 8)), dim3(CUGS_BLOCK), 0, st, up, dev_count, tk[cur],
-                       values_sorted, depths, tile_ranges, keys_sorted, ctl + 1);
+    hipLaunchKernelGGL((k_tile_ranges<K, false>), dim3(nblocks_for(up, CUGS_BLOCK * 8)), dim3(CUGS_BLOCK), 0, st, up, dev_count, tk[cur],
+                       (uint32_t)ntx, values_sorted, depths, tile_ranges, keys_sorted, ctl + 1);
     CUGS_LAUNCH_CHECK();
     return 0;
 }
@@ -692,8 +975,14 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
     if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
     // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
-    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
-                       ws.blocksum);
+    if (column_path(ntx, nty)) {
+        const uint32_t ncol = nblocks_for(un, COL_CHUNK);
+        hipLaunchKernelGGL(k_fill_blocksums_cols, dim3(ncol), dim3(COL_CHUNK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
+                           ws.blocksum, nfill, ws.colhist, ncol);
+    } else {
+        hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
+                           ws.blocksum);
+    }
     CUGS_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(CUGS_BLOCK), 0, st, ws.blocksum, nfill, ws.total,
                        reinterpret_cast<uint32_t*>(ws.total) + 4, total_mapped);
@@ -703,7 +992,7 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
 
 template <typename... A>
 int sort_pairs_dispatch(int tiles, A... args) {
-    if (tile_bits(tiles) <= 16) return sort_pairs_typed<uint16_t>(args...);
+    if (tile_bits(tiles) <= 16) return sort_pairs_typed<uint16_t>(args...);   // always when column_path() holds
     return sort_pairs_typed<uint32_t>(args...);
 }
 
@@ -846,6 +1135,18 @@ extern "C" int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const floa
 }
 
 #ifdef CUGS_DEV
+// Development build only: pairs per Gaussian from which the column-ordered emission is used (0: always).
+extern "C" int cugsdbg_sort_column_ratio(int ratio) {
+    if (ratio >= 0) g_col_min_ratio.store(ratio, std::memory_order_relaxed);
+    return g_col_min_ratio.load(std::memory_order_relaxed);
+}
+// Development build only: read (and clear) the per-phase tick sums of k_col_emit.
+extern "C" int cugsdbg_emit_profile(unsigned long long out[16]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_emit_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -100;
+    unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_emit_prof), zero, sizeof(zero)) != hipSuccess) return -100;
+    return 0;
+}
 // Debug hook (development build only, not part of the ABI header): force (0 = ballot, 1 = atomic) or query (-2) the ranking mode of the
 // radix scatter; returns the mode in effect (-1 = not probed yet).
 extern "C" int cugsdbg_sort_rank_mode(int mode) {

@@ -67,7 +67,11 @@ def test_projection_scale_modifier_and_pose(pkg, orc, dev, scale_mod, view):
 
 @pytest.mark.parametrize("n,w,h,mu_s", [(20000, 640, 360, -4.6), (3000, 250, 130, -3.0), (1, 64, 48, -2.0),
                                          (70000, 1920, 1080, -4.6),
-                                         (3000, 4112, 4112, -2.0)])   # 66049 tiles: tile ids wider than 16 bits, 3 passes
+                                         (3000, 4112, 4112, -2.0),    # 66049 tiles: tile ids wider than 16 bits, 3 passes
+                                         (3000, 4096, 64, -2.0),      # 256 tile columns: the widest column-ordered emission
+                                         (3000, 4112, 160, -2.0),     # 257 columns: 16-bit tile ids, pairs emitted in depth order
+                                         (3000, 160, 4112, -2.0),     # 257 rows: same
+                                         (400, 1920, 1080, 0.5)])     # splats covering thousands of tiles each
 def test_sort_parity_bit_exact(pkg, orc, dev, n, w, h, mu_s):
     arrays, cam = _scene(pkg, n, w, h, 0, seed=n, mu_s=mu_s)
     ref = oracle_forward(orc, arrays, cam, degree=0)
@@ -77,6 +81,35 @@ def test_sort_parity_bit_exact(pkg, orc, dev, n, w, h, mu_s):
     assert np.array_equal(np_(srt.gaussian_keys_sorted).view(np.uint64), ref["keys"])       # tile ids + depth bits
     assert np.array_equal(np_(srt.gaussian_values_sorted), ref["values"])                    # sort order
     assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])                          # per-tile spans
+
+
+@pytest.mark.parametrize("mu_s,dense", [(-4.6, False), (-3.2, True)])
+def test_sort_both_pair_routes(pkg, orc, dev, mu_s, dense):
+    """The pair-level sort has two routes to the same permutation: pairs emitted in depth order + two radix passes
+    by tile id (sparse views), or pairs emitted in tile-column order + one pass by tile row (>= 13 pairs per
+    Gaussian, sort.hip column_path_pays).  The same 1080p scene at two splat scales takes one each - exact and
+    predicted-capacity entry points - and both must give the oracle's keys, order and tile ranges."""
+    n, w, h = 50000, 1920, 1080
+    arrays, cam = _scene(pkg, n, w, h, 0, seed=17, mu_s=mu_s)
+    ref = oracle_forward(orc, arrays, cam, degree=0)
+    assert (ref["total_pairs"] >= 13 * n) == dense
+    t = lambda k: torch.from_numpy(ref[k]).to(dev)
+    args = (t("means_2d"), t("depths"), t("radii"), t("tiles_touched"), w, h)
+    R = pkg.rasterizer
+    srt = pkg.sort_gaussians(*args)
+    R._last_pairs[torch.device(dev)] = ref["total_pairs"]
+    try:
+        pend = R.sort_gaussians_predicted(*args, want_keys=True)
+        assert isinstance(pend, R.PendingSort)
+        srt2, valid = pend.finish()
+    finally:
+        R._last_pairs.pop(torch.device(dev), None)
+    assert valid
+    for out in (srt, srt2):
+        assert out.total_pairs == ref["total_pairs"]
+        assert np.array_equal(np_(out.gaussian_keys_sorted).view(np.uint64), ref["keys"])
+        assert np.array_equal(np_(out.gaussian_values_sorted), ref["values"])
+        assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"])
 
 
 _RANK_MODES_CHILD = r"""
