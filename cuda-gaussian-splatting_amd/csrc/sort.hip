@@ -369,42 +369,25 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
 // ------------------------------------------------------------------------------------
 // Pair emission in depth order
 // ------------------------------------------------------------------------------------
-// k_fill_blocksums for the column-ordered emission, COL_CHUNK Gaussians per workgroup: the same gather and block
-// sums (one per FILL_CHUNK Gaussians), and the pairs of the workgroup per tile column (colhist[column][workgroup],
-// digit-major like the radix histograms): a Gaussian adds its rectangle height to each column it covers; slots the
-// reference leaves at zero (quirk Q12) count for column 0, where their (tile 0, Gaussian 0) pairs go.
-__global__ __launch_bounds__(COL_CHUNK) void k_fill_blocksums_cols(uint32_t n, const uint32_t* __restrict__ order,
-                                                                   const int4* __restrict__ rect,
-                                                                   int4* __restrict__ rect_sorted,
-                                                                   uint32_t* __restrict__ blocksum, uint32_t nfill,
-                                                                   uint32_t* __restrict__ colhist, uint32_t ncol) {
-    __shared__ uint32_t s_wsum[COL_WAVES];
+// Column-ordered emission, step 1: the pairs of each COL_CHUNK block of the depth order per tile column
+// (colhist[column][block], digit-major like the radix histograms): a Gaussian adds its rectangle height to each
+// column it covers; slots the reference leaves at zero (quirk Q12) count for column 0, where their
+// (tile 0, Gaussian 0) pairs go.  One sequential read of the depth-ordered rectangle records.
+__global__ __launch_bounds__(COL_CHUNK) void k_col_hist(uint32_t n, const int4* __restrict__ rect_sorted,
+                                                        uint32_t* __restrict__ colhist, uint32_t ncol) {
     __shared__ uint32_t s_col[RADIX];
     const uint32_t tid = threadIdx.x;
     if (tid < RADIX) s_col[tid] = 0u;
     __syncthreads();
     const uint32_t i = blockIdx.x * COL_CHUNK + tid;
-    uint32_t acc = 0u;
-    int w = 0, h = 0, x0 = 0;
     if (i < n) {
-        const int4 r = rect[order[i]];             // the one gather per Gaussian
-        rect_sorted[i] = r;
-        acc = (uint32_t)r.w;
-        w = r.z & 0xFFFF; h = r.z >> 16; x0 = r.x;
-        if ((uint32_t)(w * h) < acc) atomicAdd(&s_col[0], acc - (uint32_t)(w * h));
+        const int4 r = rect_sorted[i];
+        const uint32_t t = (uint32_t)r.w;
+        const int w = r.z & 0xFFFF, h = r.z >> 16;
+        if ((uint32_t)(w * h) < t) atomicAdd(&s_col[0], t - (uint32_t)(w * h));
+        for (int c = 0; c < w; ++c) atomicAdd(&s_col[r.x + c], (uint32_t)h);
     }
-    for (int c = 0; c < w; ++c) atomicAdd(&s_col[x0 + c], (uint32_t)h);
-    const uint32_t inc = wave_inclusive_scan(acc);
-    if ((tid & 63u) == 63u) s_wsum[tid >> 6] = inc;
     __syncthreads();
-    constexpr int WPF = FILL_CHUNK / CUGS_WAVE;    // waves per FILL_CHUNK block
-    if (tid < COL_WAVES / WPF) {
-        const uint32_t fb = blockIdx.x * (COL_WAVES / WPF) + tid;
-        uint32_t sum = 0u;
-#pragma unroll
-        for (int v = 0; v < WPF; ++v) sum += s_wsum[tid * WPF + v];
-        if (fb < nfill) blocksum[fb] = sum;
-    }
     if (tid < RADIX) colhist[(size_t)tid * ncol + blockIdx.x] = s_col[tid];
 }
 
@@ -428,21 +411,22 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_blocksums(uint32_t n,
 
 // Single workgroup: exclusive scan of blocksum[0..nb) in place; *total = the 64-bit grand total =
 // sum(tiles_touched), the reference's cumsum[-1].item() (sorting.cu:145-146).  16 consecutive entries per
-// thread, so 4096 entries cost two barriers.  Also arms the Q12 counter (ctl[0] = 0).
-__global__ __launch_bounds__(CUGS_BLOCK) void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb,
-                                                               unsigned long long* __restrict__ total,
-                                                               uint32_t* __restrict__ ctl,
-                                                               unsigned long long* __restrict__ total_mapped) {
-    __shared__ uint32_t s_tmp[4];
+// thread, so 16384 entries cost two barriers.  Also arms the Q12 counter (ctl[0] = 0).
+constexpr int SCAN_NT = 1024;                     // one workgroup, on the critical path of the pair count: as wide as it gets
+__global__ __launch_bounds__(SCAN_NT) void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb,
+                                                            unsigned long long* __restrict__ total,
+                                                            uint32_t* __restrict__ ctl,
+                                                            unsigned long long* __restrict__ total_mapped) {
+    __shared__ uint32_t s_tmp[SCAN_NT / CUGS_WAVE];
     constexpr int PER = 16;
     unsigned long long carry = 0;
-    for (uint32_t base = 0; base < nb; base += CUGS_BLOCK * PER) {
+    for (uint32_t base = 0; base < nb; base += SCAN_NT * PER) {
         const uint32_t i0 = base + threadIdx.x * PER;
         uint32_t v[PER], sum = 0;
 #pragma unroll
         for (int e = 0; e < PER; ++e) { v[e] = (i0 + e < nb) ? blocksum[i0 + e] : 0u; sum += v[e]; }
         uint32_t chunk_total;
-        uint32_t run = (uint32_t)carry + block_exclusive_scan(sum, s_tmp, &chunk_total);
+        uint32_t run = (uint32_t)carry + block_exclusive_scan<SCAN_NT / CUGS_WAVE>(sum, s_tmp, &chunk_total);
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             if (i0 + e < nb) blocksum[i0 + e] = run;      // valid whenever the total fits int32 (checked on the host)
@@ -561,7 +545,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
 //       (column, depth) - with its height beside it;
 //   (e) scans the heights: the local slot of every item's first pair, and per column the offset between local
 //       slots and the column's run in the output (column start + pairs of the workgroups before this one, from
-//       the scanned column histogram of k_fill_blocksums_cols);
+//       the scanned column histogram of k_col_hist);
 //   (g) streams the pairs out, 64 sorted items per wave round (rounds handed out by an LDS counter), lane = item:
 //       neighbouring lanes own neighbouring runs of the output, so the `height` store instructions of a round
 //       complete each other's cache lines (writing from UNSORTED items cost 2x the HBM write requests; a slot-
@@ -927,6 +911,8 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         if (column_path(ntx, nty) && column_path_pays(un, up)) {
             // pairs emitted in tile-column order (row << 8 | column keys), then ONE stable pass by row
             const uint32_t ncol = nblocks_for(un, COL_CHUNK);
+            hipLaunchKernelGGL(k_col_hist, dim3(ncol), dim3(COL_CHUNK), 0, st, un, ws.rect[1], ws.colhist, ncol);
+            CUGS_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, ws.colhist, ws.colscan, ncol, ws.tot);
             CUGS_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_col_emit, dim3(ncol), dim3(COL_CHUNK), 0, st, un, up, dev_count, order, ws.rect[1],
@@ -975,16 +961,10 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
     if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
     // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
-    if (column_path(ntx, nty)) {
-        const uint32_t ncol = nblocks_for(un, COL_CHUNK);
-        hipLaunchKernelGGL(k_fill_blocksums_cols, dim3(ncol), dim3(COL_CHUNK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
-                           ws.blocksum, nfill, ws.colhist, ncol);
-    } else {
-        hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
-                           ws.blocksum);
-    }
+    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
+                       ws.blocksum);
     CUGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(CUGS_BLOCK), 0, st, ws.blocksum, nfill, ws.total,
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_NT), 0, st, ws.blocksum, nfill, ws.total,
                        reinterpret_cast<uint32_t*>(ws.total) + 4, total_mapped);
     CUGS_LAUNCH_CHECK();
     return 0;
