@@ -493,8 +493,11 @@ def main():
     # Clock spin-up, untimed and before the warmup: the first ~40 ms of work after the device was idle run on
     # ramping clocks (tools/step_first.py: 1.05 -> 0.90 ms/step over the first 35 steps), and a 5-step warmup ends
     # inside that ramp.  A training run sees the steady state, so that is what the K timed steps should see too.
+    # It also runs at least 128 steps (when enabled): some 50-100 steps into a process the HIP runtime stalls once for
+    # ~40 ms (tools/step_trend.py: one block of 50 steps at 1.74 instead of 0.96 ms/step; it grows a pool), which a
+    # short timed region must not straddle either.
     spin_t0, spin_steps = time.perf_counter(), 0
-    while (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:
+    while args.spinup_ms > 0 and ((time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms or spin_steps < 128):
         step(None)
         spin_steps += 1
     for _ in range(args.warmup):

@@ -191,6 +191,21 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
 # capacity sufficient (spare capacity costs a few empty workgroups, a miss costs a wasted sort and blend).
 _last_pairs = {}
 PREDICT_MARGIN = (1.10, 65536)      # capacity = estimate * 1.10 + 64 Ki
+# device -> capacity in use.  It is HELD while the estimate drifts below it (down to 80 %) and grown with 5 % to spare:
+# a capacity that follows a slowly moving pair count changes the size of the output buffers on every step, and the
+# caching allocator answers a stream of slightly different sizes with splits and, now and then, a hipMalloc (a device
+# synchronisation: ~1 ms per step at 6 M Gaussians while Adam moves the scene).
+_held_capacity = {}
+
+
+def _capacity_for(dev, estimate: int) -> int:
+    needed = min(int(estimate * PREDICT_MARGIN[0]) + PREDICT_MARGIN[1], 2147483647)
+    held = _held_capacity.get(dev)
+    if held is not None and needed <= held <= needed * 1.25:
+        return held
+    cap = needed if held is None or needed < held else min(int(needed * 1.05), 2147483647)
+    _held_capacity[dev] = cap
+    return cap
 
 
 class PendingSort:
@@ -230,7 +245,7 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
         out = sort_gaussians(means_2d, depths, radii, tiles_touched, img_w, img_h, want_keys)
         _last_pairs[dev] = out.total_pairs
         return out
-    cap = min(int(last * PREDICT_MARGIN[0]) + PREDICT_MARGIN[1], 2147483647)
+    cap = _capacity_for(dev, last)
     i32 = dict(dtype=torch.int32, device=dev)
     tile_ranges = torch.empty((ntx * nty, 2), **i32)
     keys = torch.empty((cap if want_keys else 0,), dtype=torch.int64, device=dev)

@@ -98,6 +98,7 @@ def test_sort_both_pair_routes(pkg, orc, dev, mu_s, dense):
     R = pkg.rasterizer
     srt = pkg.sort_gaussians(*args)
     R._last_pairs[torch.device(dev)] = ref["total_pairs"]
+    R._held_capacity.pop(torch.device(dev), None)
     try:
         pend = R.sort_gaussians_predicted(*args, want_keys=True)
         assert isinstance(pend, R.PendingSort)
@@ -177,6 +178,7 @@ def test_sort_predicted_capacity_path(pkg, orc, dev):
                                        (ref["total_pairs"] - 1, (1.0, 0), False),     # one short: must be detected
                                        (7, (1.0, 0), False)):
             R._last_pairs[torch.device(dev)] = last
+            R._held_capacity.pop(torch.device(dev), None)            # the capacity of THIS estimate, not one held over
             R.PREDICT_MARGIN = mg
             pend = R.sort_gaussians_predicted(*args, want_keys=True)
             assert isinstance(pend, R.PendingSort)
@@ -188,6 +190,7 @@ def test_sort_predicted_capacity_path(pkg, orc, dev):
             assert R._last_pairs[torch.device(dev)] >= ref["total_pairs"]          # running maximum, slow decay
         # nothing visible: the predicted path must leave every tile {0,0} and report zero pairs
         R._last_pairs[torch.device(dev)] = 1000
+        R._held_capacity.pop(torch.device(dev), None)
         z = torch.zeros(50, dtype=torch.int32, device=dev)
         pend = R.sort_gaussians_predicted(torch.zeros((50, 2), device=dev), torch.ones(50, device=dev), z, z, w, h)
         srt, valid = pend.finish()
@@ -205,6 +208,7 @@ def test_render_recovers_from_a_wrong_pair_prediction(pkg, orc, dev):
     small = _forward_both(pkg, orc, dev, 1500, 320, 240, 1, -4.0, (0.0, 0.0, 0.0), seed=5)
     assert R._last_pairs[torch.device(dev)] < 60000
     R._last_pairs[torch.device(dev)] = 100                       # force a gross under-prediction for the next frame
+    R._held_capacity.pop(torch.device(dev), None)
     for n, mu_s in ((40000, -3.6), (1500, -4.0)):                # far above the prediction, then far below it
         arrays, cam, model, settings, out, ref = _forward_both(pkg, orc, dev, n, 320, 240, 1, mu_s, (0.1, 0.2, 0.3), seed=n)
         assert out.total_pairs == ref["total_pairs"]
@@ -605,3 +609,23 @@ def test_forward_blend_clears_the_backward_accumulator(pkg, orc, dev):
         a, b = getattr(first, k), getattr(second, k)
         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), k
     assert pkg.render(model, cam, settings, for_backward=False).zeroed_accum is None
+
+
+def test_predicted_capacity_is_held_while_the_pair_count_drifts(pkg, dev):
+    """The capacity the predicted sort sizes its buffers with stays put while the estimate drifts below it (down to
+    80 %), grows with 5 % to spare, and follows a collapse: a capacity that tracked a slowly moving count would change
+    the output buffer size - and fragment the caching allocator - on every step."""
+    R = pkg.rasterizer
+    d = torch.device(dev)
+    R._held_capacity.pop(d, None)
+    try:
+        need = lambda e: int(e * R.PREDICT_MARGIN[0]) + R.PREDICT_MARGIN[1]
+        c0 = R._capacity_for(d, 10_000_000)
+        assert c0 == need(10_000_000)
+        assert R._capacity_for(d, 9_900_000) == c0 and R._capacity_for(d, 8_200_000) == c0      # drift: held
+        c1 = R._capacity_for(d, 10_400_000)                                                       # growth: 5 % spare
+        assert c1 == int(need(10_400_000) * 1.05) and R._capacity_for(d, 10_800_000) == c1
+        c2 = R._capacity_for(d, 2_000_000)                                                        # collapse: follow
+        assert c2 == need(2_000_000)
+    finally:
+        R._held_capacity.pop(d, None)

@@ -2,7 +2,7 @@
 wall time, host time per section (enqueue only - nothing here waits except `wait`), the wait for the sort's pair
 count, and a cProfile top list.  The step is GPU-bound when wall ~ GPU time and `wait` absorbs the slack; it is
 host-bound when the sections other than `wait` add up to the wall time.
-    python tools/host_profile.py [steps]"""
+    python tools/host_profile.py [steps] [config3|config4] [adam]"""
 import cProfile
 import os
 import pstats
@@ -21,13 +21,15 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     pkg = ge.load_package()
     dev = torch.device("cuda:0")
-    wl = pkg.scene.CONFIGS["config3"]
+    wl = pkg.scene.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "config3"]
+    use_adam = len(sys.argv) > 3 and sys.argv[3] == "adam"
     arrays = pkg.scene.make_gaussians(wl.n, wl.width, wl.height, sh_degree=wl.sh_degree, mu_s=wl.mu_s)
     model = pkg.scene.to_model(arrays, dev)
     cam = pkg.scene.make_camera(wl.width, wl.height)
     settings = pkg.RenderSettings(active_sh_degree=wl.sh_degree)
     g = torch.from_numpy(pkg.scene.make_dl_dcolor(wl.width, wl.height, seed=pkg.scene.GRAD_SEED)).to(dev)
     R = pkg.rasterizer
+    opt = pkg.FusedAdam(model) if use_adam else None
     acc = {}
     orig = {}
 
@@ -45,7 +47,7 @@ def main():
 
     def run(k):
         for _ in range(k):
-            bench.timed_step(pkg, model, cam, settings, g, None, "compact", False, None)
+            bench.timed_step(pkg, model, cam, settings, g, None, "compact", False, opt)
 
     run(30)
     torch.cuda.synchronize()
@@ -79,6 +81,9 @@ def main():
     pr.disable()
     st = pstats.Stats(pr, stream=sys.stdout)
     st.sort_stats("tottime").print_stats(18)
+    ms = torch.cuda.memory_stats(dev)
+    print("allocator: segments", ms["segment.all.current"], "reserved MiB", ms["reserved_bytes.all.current"] >> 20,
+          "device mallocs", ms["segment.all.allocated"], "frees", ms["segment.all.freed"], "retries", ms["num_alloc_retries"])
 
 
 if __name__ == "__main__":
