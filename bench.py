@@ -496,8 +496,17 @@ def main():
     # It also runs at least 128 steps (when enabled): some 50-100 steps into a process the HIP runtime stalls once for
     # ~40 ms (tools/step_trend.py: one block of 50 steps at 1.74 instead of 0.96 ms/step; it grows a pool), which a
     # short timed region must not straddle either.
+    # Under a launcher every rank must run the SAME number of steps (each one holds collectives): the ranks agree on
+    # the elapsed time (MAX over ranks) after every spin-up step.
     spin_t0, spin_steps = time.perf_counter(), 0
-    while args.spinup_ms > 0 and ((time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms or spin_steps < 128):
+    while args.spinup_ms > 0:
+        spin_ms = (time.perf_counter() - spin_t0) * 1e3
+        if launched:
+            t = torch.tensor([spin_ms], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            spin_ms = float(t.item())
+        if spin_ms >= args.spinup_ms and spin_steps >= 128:
+            break
         step(None)
         spin_steps += 1
     for _ in range(args.warmup):
