@@ -629,3 +629,25 @@ def test_predicted_capacity_is_held_while_the_pair_count_drifts(pkg, dev):
         assert c2 == need(2_000_000)
     finally:
         R._held_capacity.pop(d, None)
+
+
+@pytest.mark.parametrize("mu_s", [-4.6, -3.0])
+def test_sort_is_memory_safe_on_inconsistent_tile_counts(pkg, orc, dev, mu_s):
+    """tiles_touched is an INPUT of sort_gaussians (the reference takes its cumsum for the offsets and recomputes the
+    rectangles for the fill, sorting.cu:145,52-57): a caller may hand over counts that do not match the rectangles.
+    The result is then not defined by the reference (its fill would write into the neighbours' slots), but both pair
+    routes must stay inside their buffers: total = sum of the counts, every index a valid Gaussian, every tile range
+    inside [0, total]."""
+    n, w, h = 30000, 1280, 720
+    arrays, cam = _scene(pkg, n, w, h, 0, seed=23, mu_s=mu_s)
+    ref = oracle_forward(orc, arrays, cam, degree=0)
+    rng = np.random.default_rng(5)
+    tiles = ref["tiles_touched"].astype(np.int64)
+    bad = np.clip(tiles + rng.integers(-3, 4, size=n) * (rng.random(n) < 0.3), 0, None).astype(np.int32)
+    t = lambda k: torch.from_numpy(ref[k]).to(dev)
+    srt = pkg.sort_gaussians(t("means_2d"), t("depths"), t("radii"), torch.from_numpy(bad).to(dev), w, h)
+    total = int(bad.astype(np.int64).sum())
+    assert srt.total_pairs == total
+    vals, tr = np_(srt.gaussian_values_sorted), np_(srt.tile_ranges)
+    assert vals.shape[0] == total and vals.min() >= 0 and vals.max() < n
+    assert tr.min() >= 0 and tr.max() <= total and np.all(tr[:, 1] >= tr[:, 0])
