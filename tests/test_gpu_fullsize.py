@@ -106,3 +106,32 @@ def test_extreme_inputs_match_oracle(pkg, orc, dev, w, h, mu_s, n):
     assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"])
     assert np.array_equal(np_(out.n_contrib), ref["n_contrib"])
     assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32))
+
+
+def test_fullsize_dense_view_matches_oracle(pkg, orc, dev):
+    """The dense variant of config 3 (mu_s = -3.5: 45 M pairs, 45 per Gaussian - the column-ordered pair emission with
+    one radix pass, workgroups that stage their items in several batches): all pairs in the oracle's order, tile
+    ranges, and a band of the image and of the gradients against the oracle."""
+    wl = pkg.scene.CONFIGS["config3"]
+    arrays = pkg.scene.make_gaussians(wl.n, wl.width, wl.height, sh_degree=wl.sh_degree, mu_s=-3.5)
+    cam = pkg.scene.make_camera(wl.width, wl.height)
+    model = pkg.scene.to_model(arrays, dev)
+    settings = pkg.RenderSettings(active_sh_degree=wl.sh_degree)
+    out = pkg.render(model, cam, settings)
+    K = cam.intrinsics
+    r0, r1 = 512, 528
+    ref = orc.render(arrays, cam.rotation, cam.translation, K.fx, K.fy, K.cx, K.cy, wl.width, wl.height,
+                     active_degree=3, rows=(r0, r1))
+    assert out.total_pairs == ref["total_pairs"] and out.total_pairs >= 13 * wl.n
+    assert np.array_equal(np_(out.gaussian_indices), ref["values"])
+    assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"])
+    assert np.array_equal(np_(out.n_contrib)[r0:r1], ref["n_contrib"][r0:r1])
+    assert np.array_equal(np_(out.color)[r0:r1].view(np.uint32), ref["color"][r0:r1].view(np.uint32))
+    g = np.zeros((wl.height, wl.width, 3), np.float32)
+    g[r0:r1] = pkg.scene.make_dl_dcolor(wl.width, wl.height)[r0:r1]
+    grads = pkg.render_backward(torch.from_numpy(g).to(dev), out, model, cam, settings)
+    ref["final_T"][r0:r1] = np_(out.final_T)[r0:r1]
+    refb = orc.render_backward(g, ref, arrays, K.fx, K.fy, K.cx, K.cy, wl.width, wl.height, rows=(r0, r1))
+    for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs"):
+        got = np_(getattr(grads, name)).reshape(refb[name].shape)
+        assert max_err_over_max(got, refb[name]) <= 1e-4, name
