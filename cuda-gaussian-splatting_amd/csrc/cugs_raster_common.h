@@ -69,7 +69,7 @@ __device__ __forceinline__ int stage_record(const RasterSrc& s, int li, int end,
 // mean; along each edge q is a 1-D convex parabola (a, c > 0), minimised at the clamped vertex.
 // Rounding: the oracle's fp32 power differs from the exact one by at most ~4 ulp of
 // B = |a| X^2 + 2 |b| X Y + |c| Y^2 (X, Y the largest |offset|); q_min here carries a similar
-// error; ocml logf ~2 ulp; detexp 1 ulp.  The slack 0.01 tau + 0.05 + 4e-6 B dominates all of it
+// error; ocml logf ~2 ulp; cugs_blend_exp_q <= 1e-6 relative.  The slack 0.01 tau + 0.05 + 4e-6 B dominates all of it
 // by orders of magnitude.  Any NaN makes the final comparison false -> not culled.
 __device__ __forceinline__ bool may_touch_quad(float4 r0, float4 r1, float qx0, float qy0,
                                                float wx, float wy) {
@@ -124,11 +124,13 @@ __device__ __forceinline__ ActiveRect active_rect(unsigned long long active, flo
 // opacity, and skips become alpha = 0, which makes every later product exactly zero.
 //
 // Decisions are the oracle's, bit for bit.  FMA placement contract:
-//   u = fma(a,dx,b*dy); v = fma(b,dx,c*dy); q = fma(dx,u,dy*v); power = -0.5f*q.
-//   * power > 0 -> skipped: the exponent is replaced by -6;
-//   * power < -6 is clamped to -6: exp(-6)(1+2^-22) = 0.00248 and opacity <= 1, so alpha < 1/255 =
-//     0.00392 is certain - the oracle reaches the same skip through its alpha test (and its exp flushes
-//     below -87.3); inside [-6, 0] cugs_expf_core IS cugs_expf;
+//   u = fma(a,dx,b*dy); v = fma(b,dx,c*dy); q = fma(dx,u,dy*v); power = -0.5f*q (never formed here);
+//   e = cugs_blend_exp_q(q) = exp(-q/2) clamped below at exp(-6) (cugs_detmath.h: the oracle calls the same
+//   function, so e has the same bits there);
+//   * power > 0 <=> q < 0 -> skipped: a 0/1 factor sat(q * 2^127 + 1) on the opacity (exactly 0 for every
+//     normal negative q, exactly 1 for q >= 0);
+//   * power < -6: e = exp(-6)(1 + 1e-6) = 0.00248 and opacity <= 1, so alpha < 1/255 = 0.00392 is certain - the
+//     oracle reaches the same skip through its alpha test;
 //   * open == 0 -> alpha = 0 < 1/255 -> skipped.
 // Returns alpha if the Gaussian passes at this pixel, else exactly 0.
 struct PixelEval { float dx, dy, gx, gy, e; };
@@ -139,11 +141,10 @@ __device__ __forceinline__ float pixel_alpha_raw(float pxf, float pyf, float mx,
     r.dy = pyf - my;
     r.gx = fmaf(a, r.dx, b * r.dy);
     r.gy = fmaf(b, r.dx, c * r.dy);
-    const float power = -0.5f * fmaf(r.dx, r.gx, r.dy * r.gy);
-    float pw = fmaxf(power, -6.0f);
-    pw = (power > 0.0f) ? -6.0f : pw;
-    r.e = cugs_expf_small(pw);                                // pw in [-6, 0]: same bits as cugs_expf
-    return fminf((o * open) * r.e, 0.99f);                    // o * 1.0f is exact
+    const float q = fmaf(r.dx, r.gx, r.dy * r.gy);
+    r.e = cugs_blend_exp_q(q);
+    const float nonneg = __builtin_amdgcn_fmed3f(fmaf(q, 0x1p127f, 1.0f), 0.0f, 1.0f);   // [q >= 0], one v_fma ... clamp
+    return fminf(((o * open) * nonneg) * r.e, 0.99f);          // o * 1.0f is exact
 }
 __device__ __forceinline__ float pixel_alpha(float pxf, float pyf, float mx, float my, float a, float b,
                                              float c, float o, float open, PixelEval& r) {

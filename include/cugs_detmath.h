@@ -87,6 +87,42 @@ CUGS_HD float cugs_expf_small(float x) {
     return cugs_bits_to_float(cugs_float_to_bits(e) + ((uint32_t)(int)kf << 23));
 }
 
+/* The exponential of the blend kernels: exp(-q/2) for the quadratic form q >= 0 of a (pixel, Gaussian) pair,
+ * clamped below at exp(-6) (alpha = opacity * that < 1/255 there: the pair is skipped whatever the value), q < 0
+ * (rounding noise around the centre; the reference skips power > 0) evaluated as q = 0.  Base 2, ten plain vector
+ * instructions on gfx950 where the Cody-Waite route above takes fifteen - the blend loops are bound by
+ * instruction issue and evaluate this once per (pixel, Gaussian) step:
+ *   y = q * (-log2(e)/2), clamped to [-6 log2 e, 0];  t = y + 1.5*2^23 leaves round(y) = n in the low mantissa
+ *   bits;  f = y - n in [-1/2, 1/2];  2^f by a degree-5 minimax polynomial with constant term 1 (max rel. error 1.7e-7 in
+ *   fp32 Horner form);  2^n enters as n added to the exponent field: bits(p) + (bits(t) << 23), the constant part of
+ *   bits(t) << 23 vanishing mod 2^32.
+ * Every operation is a single correctly rounded fp32 operation (or integer), the same on the host and on the
+ * device: identical bits, hence identical skip / clamp / termination decisions in the oracle and in the kernels.
+ * Against exp(): <= 1e-6 relative over the whole range (tests/test_detmath.py); the reference's CUDA expf is a
+ * 2-ulp approximation itself, and the bar on everything downstream is 1e-4. */
+#define CUGS_BLEND_K (-0.72134752044448170368f)        /* -log2(e)/2 */
+#define CUGS_BLEND_YMIN (-8.6561702453337804f)         /* -6 log2(e) */
+CUGS_HD float cugs_blend_exp_q(float q) {
+    float y = q * CUGS_BLEND_K;
+#if defined(__HIP_DEVICE_COMPILE__)
+    y = __builtin_amdgcn_fmed3f(y, CUGS_BLEND_YMIN, 0.0f);
+#else
+    y = (y < CUGS_BLEND_YMIN) ? CUGS_BLEND_YMIN : y;
+    y = (y > 0.0f) ? 0.0f : y;
+#endif
+    const float magic = 12582912.0f;                   /* 1.5 * 2^23 */
+    float t = y + magic;
+    float nf = t - magic;
+    float f = y - nf;
+    float p = 0x1.5c37d0p-10f;
+    p = fmaf(p, f, 0x1.3d01dep-7f);
+    p = fmaf(p, f, 0x1.c6b626p-5f);
+    p = fmaf(p, f, 0x1.ebf96ap-3f);
+    p = fmaf(p, f, 0x1.62e42ap-1f);
+    p = fmaf(p, f, 1.0f);                              /* constant term exactly 1: exp(-0/2) == 1 */
+    return cugs_bits_to_float(cugs_float_to_bits(p) + (cugs_float_to_bits(t) << 23));
+}
+
 /* exp(x), all inputs: NaN -> NaN, x > 88.72 -> +inf, x < -87.3 -> 0 (results
  * below FLT_MIN are flushed: nothing on this path distinguishes them). */
 CUGS_HD float cugs_expf(float x) {

@@ -11,8 +11,9 @@
  * multiply-adds are explicit fmaf calls at the places listed in DESIGN.md
  * ("FMA placement contract"), which the HIP kernels mirror, so that every
  * integer output and every alpha / transmittance DECISION is bit-identical
- * between this file and the GPU.  expf / rsqrtf / sigmoid come from
- * include/cugs_detmath.h for the same reason (see that header).
+ * between this file and the GPU.  expf / rsqrtf / sigmoid - and the blend's
+ * exp(power) as cugs_blend_exp_q(q), <= 1e-6 relative from exp(-q/2) - come
+ * from include/cugs_detmath.h for the same reason (see that header).
  *
  * PARITY STATUS (also in DESIGN.md): the reference's kernels are CUDA and
  * cannot run here; its tests hold no golden numbers for this path.  Pinned by:
@@ -430,8 +431,10 @@ int orc_sort(int n, const float* means_2d, const float* depths, const int32_t* r
 /* q = fma(dx,u,dy*v); power = -0.5f*q.                                      */
 /* Returns 0 when the Gaussian is skipped at this pixel.                     */
 /* ------------------------------------------------------------------------- */
+/* exp(power) is cugs_blend_exp_q(q) (include/cugs_detmath.h): exp(-q/2), evaluated in base 2 and clamped below */
+/* at exp(-6), where opacity * it < 1/255 and the pair is skipped here as in the reference.                     */
 static inline int eval_alpha(float pxf, float pyf, float mx, float my, float a, float b, float c,
-                             float opacity, float* dx_o, float* dy_o, float* power_o,
+                             float opacity, float* dx_o, float* dy_o, float* exp_power_o,
                              float* alpha_o) {
     float dx = pxf - mx;
     float dy = pyf - my;
@@ -440,10 +443,11 @@ static inline int eval_alpha(float pxf, float pyf, float mx, float my, float a, 
     float q = fmaf(dx, u, dy * v);
     float power = -0.5f * q;
     if (power > 0.0f) return 0;
-    float alpha = opacity * cugs_expf(power);
+    float exp_power = cugs_blend_exp_q(q);
+    float alpha = opacity * exp_power;
     alpha = fminf(alpha, 0.99f);
     if (alpha < 1.0f / 255.0f) return 0;
-    *dx_o = dx; *dy_o = dy; *power_o = power; *alpha_o = alpha;
+    *dx_o = dx; *dy_o = dy; *exp_power_o = exp_power; *alpha_o = alpha;
     return 1;
 }
 
@@ -532,9 +536,9 @@ void orc_rasterize_backward_rows(int img_w, int img_h, int row0, int row1, const
                 float a = cov_2d_inv[g * 3 + 0], b = cov_2d_inv[g * 3 + 1],
                       c = cov_2d_inv[g * 3 + 2];
                 float o = opacities[g];
-                float dx, dy, power, alpha;
+                float dx, dy, exp_power, alpha;
                 if (!eval_alpha(pxf, pyf, means_2d[g * 2], means_2d[g * 2 + 1], a, b, c, o, &dx,
-                                &dy, &power, &alpha))
+                                &dy, &exp_power, &alpha))
                     continue;
                 found++;
                 if (found > max_contrib) break;              /* :141-145 */
@@ -548,7 +552,6 @@ void orc_rasterize_backward_rows(int img_w, int img_h, int row0, int row1, const
                 dL_dalpha += dC1 * (T * r1 - S1 / one_minus_alpha);
                 dL_dalpha += dC2 * (T * r2 - S2 / one_minus_alpha);
                 S0 += weight * r0; S1 += weight * r1; S2 += weight * r2;
-                float exp_power = cugs_expf(power);
                 float dL_dopa = dL_dalpha * exp_power;
                 float dL_dpower = dL_dalpha * alpha;
                 if (o * exp_power >= 0.99f) { dL_dopa = 0.0f; dL_dpower = 0.0f; }
@@ -827,6 +830,9 @@ void orc_expf_small_array(int64_t n, const float* x, float* y) {
 }
 void orc_expf_array(int64_t n, const float* x, float* y) {
     for (int64_t i = 0; i < n; ++i) y[i] = cugs_expf(x[i]);
+}
+void orc_blend_exp_q_array(int64_t n, const float* q, float* y) {
+    for (int64_t i = 0; i < n; ++i) y[i] = cugs_blend_exp_q(q[i]);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -184,6 +184,14 @@ def expf_small(x: np.ndarray) -> np.ndarray:
     return y.reshape(np.shape(x))
 
 
+def blend_exp_q(q: np.ndarray) -> np.ndarray:
+    """cugs_blend_exp_q: the blend's exp(-q/2), clamped below at exp(-6) (include/cugs_detmath.h)."""
+    qi = _f(q).reshape(-1)
+    y = np.empty_like(qi)
+    _lib.orc_blend_exp_q_array(C.c_int64(qi.size), _p(qi), _p(y))
+    return y.reshape(np.shape(q))
+
+
 # ---- whole pipeline on numpy arrays (what tests compare the GPU against) ----------------
 def render(model: Dict[str, np.ndarray], rotation, translation, fx, fy, cx, cy, w, h, bg=(0.0, 0.0, 0.0),
            active_degree=3, scale_mod=1.0, rows=None) -> Dict[str, np.ndarray]:

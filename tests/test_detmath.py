@@ -47,3 +47,23 @@ def test_expf_small_is_bit_identical_on_its_range(orc):
     x = np.concatenate([rng.uniform(-6.0, 0.0, 1_000_000), rng.uniform(-80.0, 80.0, 300_000),
                         np.linspace(-6.0, 0.0, 100_001), [0.0, -0.0, -6.0, -80.0, 80.0]]).astype(np.float32)
     assert np.array_equal(orc.expf_small(x).view(np.uint32), orc.expf(x).view(np.uint32))
+
+
+def test_blend_exp_q_against_libm(orc):
+    """cugs_blend_exp_q(q) = exp(-q/2) for q in [0, 12] (base-2 range reduction + degree-5 polynomial, what the blend
+    kernels and the oracle evaluate per (pixel, Gaussian) pair): within 1e-6 relative of the exact value, non-increasing
+    up to its own error, exactly 1 at q <= 0, and clamped at exp(-6) beyond q = 12 - where opacity * it < 1/255 whatever
+    the opacity, so the pair is skipped either way."""
+    rng = np.random.default_rng(3)
+    q = np.concatenate([rng.uniform(0.0, 12.0, 2_000_000), np.linspace(0.0, 12.0, 400_001),
+                        np.float32(2.0) ** -np.arange(0, 40, dtype=np.float32)]).astype(np.float32)
+    got = orc.blend_exp_q(q).astype(np.float64)
+    want = np.exp(-0.5 * q.astype(np.float64))
+    assert np.max(np.abs(got - want) / want) <= 1.0e-6
+    qs = np.sort(q)
+    e = orc.blend_exp_q(qs).astype(np.float64)
+    assert np.all(np.diff(e) <= 4e-7 * e[1:])                 # non-increasing up to the polynomial's own error
+    edge = orc.blend_exp_q(np.array([0.0, -0.0, -1.0, -1e-30, 12.0, 13.0, 1e9, np.inf], np.float32))
+    assert edge[0] == 1.0 and edge[1] == 1.0 and edge[2] == 1.0 and edge[3] == 1.0
+    assert edge[4] == edge[5] == edge[6] == edge[7] and abs(float(edge[4]) / np.exp(-6.0) - 1.0) <= 1e-6
+    assert float(edge[4]) < 1.0 / 255.0
