@@ -78,15 +78,6 @@ CUGS_HD float cugs_expf_core(float x) {
     return (e * cugs_pow2i(k1)) * cugs_pow2i(k2);
 }
 
-/* The same function for |x| <= 80 (the blend evaluates it on [-6, 0] only): there the result is a normal
- * number, so the two exact scalings are one addition of k to the exponent field - identical bits, five
- * instructions fewer (tests/test_detmath.py compares the two on that range). */
-CUGS_HD float cugs_expf_small(float x) {
-    float kf;
-    float e = cugs_expf_mant(x, &kf);
-    return cugs_bits_to_float(cugs_float_to_bits(e) + ((uint32_t)(int)kf << 23));
-}
-
 /* The exponential of the blend kernels: exp(-q/2) for the quadratic form q >= 0 of a (pixel, Gaussian) pair,
  * clamped below at exp(-6) (alpha = opacity * that < 1/255 there: the pair is skipped whatever the value), q < 0
  * (rounding noise around the centre; the reference skips power > 0) evaluated as q = 0.  Base 2, ten plain vector

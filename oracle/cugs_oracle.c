@@ -825,9 +825,6 @@ float orc_position_lr(int step, float lr_init, float lr_final, int max_steps) {
 
 /* Exposed for tests/test_detmath.py. */
 float orc_expf(float x) { return cugs_expf(x); }
-void orc_expf_small_array(int64_t n, const float* x, float* y) {
-    for (int64_t i = 0; i < n; ++i) y[i] = cugs_expf_small(x[i]);
-}
 void orc_expf_array(int64_t n, const float* x, float* y) {
     for (int64_t i = 0; i < n; ++i) y[i] = cugs_expf(x[i]);
 }

@@ -177,13 +177,6 @@ def expf(x: np.ndarray) -> np.ndarray:
     return y.reshape(np.shape(x))
 
 
-def expf_small(x: np.ndarray) -> np.ndarray:
-    xi = _f(x).reshape(-1)
-    y = np.empty_like(xi)
-    _lib.orc_expf_small_array(C.c_int64(xi.size), _p(xi), _p(y))
-    return y.reshape(np.shape(x))
-
-
 def blend_exp_q(q: np.ndarray) -> np.ndarray:
     """cugs_blend_exp_q: the blend's exp(-q/2), clamped below at exp(-6) (include/cugs_detmath.h)."""
     qi = _f(q).reshape(-1)
