@@ -127,8 +127,8 @@ __device__ __forceinline__ ActiveRect active_rect(unsigned long long active, flo
 //   u = fma(a,dx,b*dy); v = fma(b,dx,c*dy); q = fma(dx,u,dy*v); power = -0.5f*q (never formed here);
 //   e = cugs_blend_exp_q(q) = exp(-q/2) clamped below at exp(-6) (cugs_detmath.h: the oracle calls the same
 //   function, so e has the same bits there);
-//   * power > 0 <=> q < 0 -> skipped: a 0/1 factor sat(q * 2^127 + 1) on the opacity (exactly 0 for every
-//     normal negative q, exactly 1 for q >= 0);
+//   * power > 0 <=> q < 0 -> skipped: q * 2^127 + 1 (<= -1 for every normal negative q, >= 1 for q >= 0) joins
+//     the minimum with 0.99, so alpha comes out negative and fails the 1/255 test;
 //   * power < -6: e = exp(-6)(1 + 1e-6) = 0.00248 and opacity <= 1, so alpha < 1/255 = 0.00392 is certain - the
 //     oracle reaches the same skip through its alpha test;
 //   * open == 0 -> alpha = 0 < 1/255 -> skipped.
@@ -143,8 +143,10 @@ __device__ __forceinline__ float pixel_alpha_raw(float pxf, float pyf, float mx,
     r.gy = fmaf(b, r.dx, c * r.dy);
     const float q = fmaf(r.dx, r.gx, r.dy * r.gy);
     r.e = cugs_blend_exp_q(q);
-    const float nonneg = __builtin_amdgcn_fmed3f(fmaf(q, 0x1p127f, 1.0f), 0.0f, 1.0f);   // [q >= 0], one v_fma ... clamp
-    return fminf(((o * open) * nonneg) * r.e, 0.99f);          // o * 1.0f is exact
+    // q * 2^127 + 1 is >= 1 for q >= 0 and <= -1 for every normal q < 0: as third operand of the minimum it leaves
+    // min(alpha, 0.99) alone or turns it negative - below 1/255, skipped (one v_fma + one v_min3)
+    const float gate = fmaf(q, 0x1p127f, 1.0f);
+    return __builtin_fminf(__builtin_fminf((o * open) * r.e, 0.99f), gate);   // o * 1.0f is exact
 }
 __device__ __forceinline__ float pixel_alpha(float pxf, float pyf, float mx, float my, float a, float b,
                                              float c, float o, float open, PixelEval& r) {
