@@ -62,11 +62,30 @@ int main(int argc, char** argv) {
                                 std::max(grads.dL_dpositions.abs().max().item<double>(), 1e-30);
             printf("glue_repack rel_dsh=%.3e rel_dpos=%.3e\n", diff / std::max(scale, 1e-30), dpos);
         }
+        // a second copy of the model takes the FUSED route: backward with the optimizer step inside the projection
+        // backward (cugs_project_backward_adam), on an accumulator the forward blend cleared
+        cugs_hip::ModelTensors m2{m.positions.clone(), m.sh_coeffs.clone(), m.opacities.clone(), m.rotations.clone(),
+                                  m.scales.clone()};
         cugs_hip::FusedAdam opt({m.positions, m.sh_coeffs, m.opacities, m.scales, m.rotations},
                                 {1.6e-4f, 2.5e-3f, 0.05f, 5e-3f, 1e-3f});
         opt.apply_gradients(grads);
         opt.step();
         fprintf(stderr, "[driver] adam done\n");
+        {
+            cugs_hip::FusedAdam opt2({m2.positions, m2.sh_coeffs, m2.opacities, m2.scales, m2.rotations},
+                                     {1.6e-4f, 2.5e-3f, 0.05f, 5e-3f, 1e-3f});
+            auto out2 = cugs_hip::render(m2, cam, st);
+            const bool cleared = out2.zeroed_accum.defined() && out2.zeroed_accum.abs().max().item<float>() == 0.0f;
+            auto g2 = cugs_hip::render_backward(g, out2, m2, cam, st, &opt2);
+            const bool consumed = !out2.zeroed_accum.defined() && !g2.dL_dpositions.defined();
+            // the two routes ran separate blends (atomics order sums differently): equal up to that
+            const double dpos = (m2.positions - m.positions).abs().max().item<double>();
+            const double dsh = (m2.sh_coeffs - m.sh_coeffs).abs().max().item<double>();
+            const double dm2d = (g2.dL_dmeans_2d - grads.dL_dmeans_2d).abs().max().item<double>() /
+                                std::max(grads.dL_dmeans_2d.abs().max().item<double>(), 1e-30);
+            printf("fused_adam cleared=%d consumed=%d dpos=%.3e dsh=%.3e rel_dmeans2d=%.3e\n", cleared ? 1 : 0,
+                   consumed ? 1 : 0, dpos, dsh, dm2d);
+        }
         // N1 through the C++ host: loss + dL/dcolor of the render against the flipped image as a target
         auto lg = cugs_hip::combined_loss_and_grad(out.color, out.color.flip(0).contiguous());
         save(d + "/out_loss.bin", lg.loss.reshape({1}));

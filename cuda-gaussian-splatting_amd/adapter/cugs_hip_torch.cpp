@@ -112,7 +112,7 @@ SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor&
 ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tensor& cov_2d_inv, const torch::Tensor& rgb,
                                 const torch::Tensor& opacities, const torch::Tensor& tile_ranges,
                                 const torch::Tensor& gaussian_indices, int img_w, int img_h,
-                                const float background[3], const torch::Tensor& packed) {
+                                const float background[3], const torch::Tensor& packed, const torch::Tensor& zero_buf) {
     TORCH_CHECK(means_2d.is_cuda(), "means_2d must be on CUDA");
     ForwardOutput o;
     o.color = torch::empty({img_h, img_w, 3}, fopt(means_2d));
@@ -121,6 +121,16 @@ ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tens
     if (img_w == 0 || img_h == 0) return o;
     auto m = means_2d.contiguous(), c = cov_2d_inv.contiguous(), r = rgb.contiguous(), op = opacities.contiguous();
     auto tr = tile_ranges.contiguous(), gi = gaussian_indices.contiguous();
+    if (zero_buf.defined()) {                                   // the blend also clears the backward's accumulator
+        TORCH_CHECK(zero_buf.is_contiguous() && zero_buf.scalar_type() == torch::kFloat32 && zero_buf.numel() % 4 == 0,
+                    "zero_buf must be a contiguous float32 tensor of a multiple of four elements");
+        check(cugs_rasterize_forward_zero(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m),
+                                          ptr<float>(c), ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(o.color),
+                                          ptr<float>(o.final_T), ptr<int32_t>(o.n_contrib), zero_buf.data_ptr(),
+                                          static_cast<size_t>(zero_buf.numel()) * sizeof(float), stream_of(means_2d)),
+              "cugs_rasterize_forward_zero");
+        return o;
+    }
     check(cugs_rasterize_forward(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m), ptr<float>(c),
                                  ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(o.color),
                                  ptr<float>(o.final_T), ptr<int32_t>(o.n_contrib), stream_of(means_2d)),
@@ -134,11 +144,15 @@ RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const
                                            const torch::Tensor& gaussian_indices, const torch::Tensor& final_T,
                                            const torch::Tensor& n_contrib, int img_w, int img_h,
                                            const float background[3], int n_gaussians, const torch::Tensor& packed,
-                                           bool unpack) {
+                                           bool unpack, const torch::Tensor& zeroed_accum) {
     TORCH_CHECK(dL_dcolor.is_cuda(), "dL_dcolor must be on CUDA");
     const int64_t n = n_gaussians;
     RasterizeBackwardOutput o;
-    o.grad_accum = torch::empty({n, CUGS_GRAD_STRIDE}, fopt(dL_dcolor));
+    const bool prezeroed = zeroed_accum.defined();
+    if (prezeroed)
+        TORCH_CHECK(zeroed_accum.is_contiguous() && zeroed_accum.dim() == 2 && zeroed_accum.size(0) == n &&
+                    zeroed_accum.size(1) == CUGS_GRAD_STRIDE, "zeroed_accum must be a contiguous [N, 16] float32 tensor");
+    o.grad_accum = prezeroed ? zeroed_accum : torch::empty({n, CUGS_GRAD_STRIDE}, fopt(dL_dcolor));
     if (unpack) {
         o.dL_drgb = torch::empty({n, 3}, fopt(dL_dcolor));
         o.dL_dopacity_act = torch::empty({n}, fopt(dL_dcolor));
@@ -149,12 +163,13 @@ RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const
     auto g = dL_dcolor.contiguous(), m = means_2d.contiguous(), c = cov_2d_inv.contiguous(), r = rgb.contiguous();
     auto op = opacities.contiguous(), tr = tile_ranges.contiguous(), gi = gaussian_indices.contiguous();
     auto ft = final_T.contiguous(), nc = n_contrib.contiguous();
-    check(cugs_rasterize_backward(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m), ptr<float>(c),
-                                  ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(g), ptr<float>(ft),
-                                  ptr<int32_t>(nc), n, ptr<float>(o.grad_accum), ptr<float>(o.dL_drgb),
-                                  ptr<float>(o.dL_dopacity_act), ptr<float>(o.dL_dmeans_2d), ptr<float>(o.dL_dcov_2d_inv),
-                                  stream_of(dL_dcolor)),
-          "cugs_rasterize_backward");
+    auto entry = prezeroed ? cugs_rasterize_backward_prezeroed : cugs_rasterize_backward;
+    check(entry(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m), ptr<float>(c),
+                ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(g), ptr<float>(ft),
+                ptr<int32_t>(nc), n, ptr<float>(o.grad_accum), ptr<float>(o.dL_drgb),
+                ptr<float>(o.dL_dopacity_act), ptr<float>(o.dL_dmeans_2d), ptr<float>(o.dL_dcov_2d_inv),
+                stream_of(dL_dcolor)),
+          prezeroed ? "cugs_rasterize_backward_prezeroed" : "cugs_rasterize_backward");
     return o;
 }
 
@@ -239,7 +254,8 @@ static int max_sh_degree(const torch::Tensor& sh) {                             
     return sh.defined() ? static_cast<int>(std::sqrt(static_cast<float>(sh.size(2)))) - 1 : 0;
 }
 
-RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings) {
+RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings,
+                    bool for_backward) {
     TORCH_CHECK(model.positions.defined() && model.positions.is_cuda(), "GaussianModel must be on CUDA device");
     const int64_t n = model.positions.size(0);
     const int w = camera.width, h = camera.height;
@@ -264,9 +280,11 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     static thread_local auto& last_pairs = *new std::map<int, int64_t>();
     static thread_local auto& pinned = *new std::map<int, torch::Tensor>();
     const int dev_index = model.positions.device().index();
+    // the backward blend's accumulator, cleared in passing by the forward blend (issue-bound, HBM idle)
+    torch::Tensor accum = for_backward ? torch::empty({n, CUGS_GRAD_STRIDE}, fopt(model.positions)) : torch::Tensor();
     auto blend = [&](const SortingOutput& s) {
         return rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
-                                 s.gaussian_values_sorted, w, h, settings.background, proj.packed);
+                                 s.gaussian_values_sorted, w, h, settings.background, proj.packed, accum);
     };
     SortingOutput srt;
     ForwardOutput fwd;
@@ -315,11 +333,12 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     o.means_2d = proj.means_2d; o.depths = proj.depths; o.cov_2d_inv = proj.cov_2d_inv; o.radii = proj.radii;
     o.rgb = proj.rgb; o.opacities_act = proj.opacities_act;
     o.gaussian_indices = srt.gaussian_values_sorted; o.tile_ranges = srt.tile_ranges; o.packed = proj.packed;
+    o.zeroed_accum = accum;
     return o;
 }
 
 BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutput& ro, const ModelTensors& model,
-                               const cugs_camera& camera, const RenderSettings& settings) {
+                               const cugs_camera& camera, const RenderSettings& settings, FusedAdam* fused) {
     TORCH_CHECK(dL_dcolor.is_cuda(), "dL_dcolor must be on CUDA device");                             // rasterizer.cpp:122-124
     TORCH_CHECK(dL_dcolor.dim() == 3 && dL_dcolor.size(2) == 3, "dL_dcolor must be [H, W, 3]");
     const int64_t n = model.positions.size(0);
@@ -341,10 +360,28 @@ BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutpu
         check(cugs_pack_projected(n, ptr<float>(m), ptr<float>(c), ptr<float>(r), ptr<float>(op), ptr<float>(packed),
                                   stream_of(dL_dcolor)), "cugs_pack_projected");
     }
+    // the accumulator render() had the forward blend clear is good for ONE backward
+    torch::Tensor zeroed = ro.zeroed_accum;
+    ro.zeroed_accum = torch::Tensor();
+    if (zeroed.defined() && (zeroed.dim() != 2 || zeroed.size(0) != n)) zeroed = torch::Tensor();
     auto rb = rasterize_backward(dL_dcolor, ro.means_2d, ro.cov_2d_inv, ro.rgb, ro.opacities_act, ro.tile_ranges,
                                  ro.gaussian_indices, ro.final_T, ro.n_contrib, camera.width, camera.height,
-                                 settings.background, static_cast<int>(n), packed, /*unpack=*/false);
+                                 settings.background, static_cast<int>(n), packed, /*unpack=*/false, zeroed);
     o.dL_dmeans_2d = torch::empty({n, 2}, fopt(dL_dcolor));
+    if (fused) {                                                // a8 + a9 + a11 in one launch, parameters updated in place
+        const auto& pr = fused->params();
+        TORCH_CHECK(pr[0].data_ptr() == model.positions.data_ptr() && pr[1].data_ptr() == model.sh_coeffs.data_ptr(),
+                    "the fused optimizer step needs the FusedAdam that was built on this model");
+        const cugs_adam_fused adam = fused->begin_fused_step();
+        auto radii = ro.radii.contiguous(), rgbc = ro.rgb.contiguous();
+        check(cugs_project_backward_adam(n, static_cast<int>(model.sh_coeffs.size(2)), degree, ptr<float>(model.positions),
+                                         ptr<float>(model.rotations), ptr<float>(model.scales), ptr<float>(model.opacities),
+                                         ptr<float>(model.sh_coeffs), ptr<int32_t>(radii), ptr<float>(rgbc), &camera,
+                                         settings.scale_modifier, ptr<float>(rb.grad_accum), &adam,
+                                         ptr<float>(o.dL_dmeans_2d), stream_of(dL_dcolor)),
+              "cugs_project_backward_adam");
+        return o;
+    }
     auto pb = project_backward_impl(&rb.grad_accum, &ro.rgb, &o.dL_dmeans_2d, {}, {}, {}, {}, model.positions,
                                     model.rotations, model.scales, model.opacities, model.sh_coeffs, ro.radii, camera, degree,
                                     settings.scale_modifier);
@@ -405,6 +442,20 @@ void FusedAdam::apply_gradients(const BackwardOutput& g) {        // references,
     grads_ = {g.dL_dpositions, g.dL_dsh_coeffs, g.dL_dopacities, g.dL_dscales, g.dL_drotations};
 }
 void FusedAdam::zero_grad() { for (auto& g : grads_) g = torch::Tensor(); }
+cugs_adam_fused FusedAdam::begin_fused_step() {
+    ++step_count_;
+    cugs_adam_fused a{};
+    cugs_adam_bias_correction(h_.beta1, h_.beta2, step_count_, &a.bc1, &a.bc2);
+    for (int i = 0; i < 5; ++i) {
+        TORCH_CHECK(params_[i].is_cuda() && params_[i].is_contiguous() && params_[i].scalar_type() == torch::kFloat32 &&
+                    m_[i].is_contiguous() && v_[i].is_contiguous(),
+                    "FusedAdam: the fused step needs contiguous float32 CUDA parameters and moments");
+        a.m[i] = m_[i].data_ptr<float>(); a.v[i] = v_[i].data_ptr<float>(); a.lr[i] = lrs_[i];
+    }
+    a.beta1 = h_.beta1; a.beta2 = h_.beta2; a.eps = h_.eps;
+    zero_grad();
+    return a;
+}
 void FusedAdam::step() {
     ++step_count_;
     float bc1, bc2;

@@ -40,6 +40,9 @@ struct RenderOutput {              // rasterizer/rasterizer.hpp:27-46
     torch::Tensor color, final_T, n_contrib, means_2d, depths, cov_2d_inv, radii, rgb, opacities_act,
         gaussian_indices, tile_ranges;
     torch::Tensor packed;
+    // [N, 16] accumulator of the blend backward, already cleared by the forward blend (which leaves HBM idle); handed
+    // to ONE render_backward, which takes it out of the struct (hence mutable)
+    mutable torch::Tensor zeroed_accum;
 };
 struct BackwardOutput { torch::Tensor dL_dpositions, dL_drotations, dL_dscales, dL_dopacities, dL_dsh_coeffs, dL_dmeans_2d; };
 
@@ -53,14 +56,15 @@ ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tens
                                 const torch::Tensor& rgb, const torch::Tensor& opacities,
                                 const torch::Tensor& tile_ranges, const torch::Tensor& gaussian_indices,
                                 int img_w, int img_h, const float background[3],
-                                const torch::Tensor& packed = {});
+                                const torch::Tensor& packed = {}, const torch::Tensor& zero_buf = {});
 RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const torch::Tensor& means_2d,
                                            const torch::Tensor& cov_2d_inv, const torch::Tensor& rgb,
                                            const torch::Tensor& opacities, const torch::Tensor& tile_ranges,
                                            const torch::Tensor& gaussian_indices, const torch::Tensor& final_T,
                                            const torch::Tensor& n_contrib, int img_w, int img_h,
                                            const float background[3], int n_gaussians,
-                                           const torch::Tensor& packed = {}, bool unpack = true);
+                                           const torch::Tensor& packed = {}, bool unpack = true,
+                                           const torch::Tensor& zeroed_accum = {});
 ProjectionBackwardOutput project_backward(const torch::Tensor& dL_dmeans_2d, const torch::Tensor& dL_dcov_2d_inv,
                                           const torch::Tensor& dL_drgb, const torch::Tensor& dL_dopacity_act,
                                           const torch::Tensor& positions, const torch::Tensor& rotations,
@@ -72,9 +76,16 @@ torch::Tensor evaluate_sh_cuda(int degree, const torch::Tensor& sh_coeffs, const
 torch::Tensor evaluate_sh_backward_cuda(int degree, const torch::Tensor& sh_coeffs, const torch::Tensor& directions,
                                         const torch::Tensor& dL_dcolor);
 
-RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings);
+// `for_backward` = false (evaluation, viewer; not in the reference): no accumulator is prepared for a backward pass.
+RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings,
+                    bool for_backward = true);
+class FusedAdam;
+// `fused` (optional, not in the reference; single-GPU training): the projection backward applies the optimizer step to
+// the model in place (cugs_project_backward_adam) and the five parameter gradients are never materialised (undefined
+// in the result; dL_dmeans_2d is returned) - bit for bit render_backward + apply_gradients + step.
 BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutput& render_out,
-                               const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings);
+                               const ModelTensors& model, const cugs_camera& camera, const RenderSettings& settings,
+                               FusedAdam* fused = nullptr);
 
 // training/loss.hpp:21-52 + the autograd step of trainer.cpp:214-217 in two launches.
 // Scalars are 0-dim device tensors, as in the reference.
@@ -94,6 +105,10 @@ public:
     void set_lr(int group, float lr) { lrs_[group] = lr; }
     float get_lr(int group) const { return lrs_[group]; }
     void step();
+    // The optimizer half of cugs_project_backward_adam: counts the step, returns moments / learning rates / bias
+    // corrections for the launch that updates the parameters in place (they must be contiguous float32).
+    cugs_adam_fused begin_fused_step();
+    const std::array<torch::Tensor, 5>& params() const { return params_; }
 private:
     friend class DensificationController;      // carries m_/v_ through clone/split/prune
     friend bool write_gaussian_ply(const std::string&, const ModelTensors&, const FusedAdam*);

@@ -42,6 +42,12 @@ def test_cpp_adapter_matches_python_host(pkg, dev, tmp_path):
     # gets the records rebuilt and runs the same packed blend kernel: same gradients up to atomic order
     repack = [l for l in res.stdout.splitlines() if l.startswith("glue_repack ")][0].split()
     assert float(repack[1].split("=")[1]) <= 1e-5 and float(repack[2].split("=")[1]) <= 1e-5, repack
+    # the fused route of the C++ host: the forward blend cleared the accumulator, render_backward took it out of the
+    # RenderOutput, the optimizer step ran inside the projection backward (no gradient tensors), and the updated
+    # model equals the one from render_backward + apply_gradients + step up to the atomics' summation order
+    fused = dict(kv.split("=") for kv in [l for l in res.stdout.splitlines() if l.startswith("fused_adam ")][0].split()[1:])
+    assert fused["cleared"] == "1" and fused["consumed"] == "1", fused
+    assert float(fused["dpos"]) <= 1e-7 and float(fused["dsh"]) <= 1e-5 and float(fused["rel_dmeans2d"]) <= 1e-5, fused
 
     model = pkg.scene.to_model(arrays, dev)
     settings = pkg.RenderSettings(background=bg, active_sh_degree=deg)
