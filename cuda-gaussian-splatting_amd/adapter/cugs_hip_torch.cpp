@@ -294,7 +294,15 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
         fwd = blend(srt);
     } else {
-        const int64_t cap = std::min<int64_t>(known->second + known->second / 10 + 65536, 2147483647ll);
+        // capacity = estimate * 1.10 + 64 Ki, HELD while the estimate drifts below it (down to 80 %) and grown with 5 %
+        // to spare: buffer sizes that follow a slowly moving pair count fragment the caching allocator
+        static thread_local auto& held_cap = *new std::map<int, int64_t>();
+        const int64_t needed = std::min<int64_t>(known->second + known->second / 10 + 65536, 2147483647ll);
+        int64_t cap = needed;
+        auto held = held_cap.find(dev_index);
+        if (held != held_cap.end() && needed <= held->second && held->second <= needed + needed / 4) cap = held->second;
+        else if (held != held_cap.end() && needed > held->second) cap = std::min<int64_t>(needed + needed / 20, 2147483647ll);
+        held_cap[dev_index] = cap;
         if (!pinned.count(dev_index)) pinned[dev_index] = torch::zeros({1}, torch::kInt64).pin_memory();
         auto total = pinned[dev_index];
         void* st = stream_of(proj.means_2d);
