@@ -10,7 +10,7 @@ not a Python identifier; load it under the module name `cugs_amd` via __graft_en
 """
 from ._lib import CugsError, LIB_PATH, version  # noqa: F401  (loads libcugs_hip.so or raises)
 from .types import (BackwardOutput, CameraInfo, CameraIntrinsics, ForwardOutput, GaussianModel,  # noqa: F401
-                    ProjectionBackwardOutput, ProjectionOutput, RasterizeBackwardOutput, RenderOutput,
+                    PredictionMiss, ProjectionBackwardOutput, ProjectionOutput, RasterizeBackwardOutput, RenderOutput,
                     RenderSettings, SortingOutput, K_MAX_SH_DEGREE, K_TILE_SIZE, sh_coeff_count)
 from .rasterizer import (evaluate_sh_backward_cuda, evaluate_sh_cuda, project_backward,  # noqa: F401
                          project_gaussians, rasterize_backward, rasterize_forward, render, render_backward,

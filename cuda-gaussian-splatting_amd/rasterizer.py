@@ -396,8 +396,13 @@ def sh_backward_views(degree: int, positions: torch.Tensor, gated_rgb_views: tor
 # --------------------------------------------------------------------------------------
 # render / render_backward (rasterizer.cpp:22-186)
 # --------------------------------------------------------------------------------------
-def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, for_backward: bool = True) -> RenderOutput:
-    """`for_backward=False` (evaluation, viewer): skips preparing the backward's accumulator (64 B/Gaussian)."""
+def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, for_backward: bool = True,
+           defer_count: bool = False) -> RenderOutput:
+    """`for_backward=False` (evaluation, viewer): skips preparing the backward's accumulator (64 B/Gaussian).
+    `defer_count=True` (training loops; not in the reference): returns without waiting for the sort's pair count, so
+    the caller can queue the loss behind the forward blend before the host blocks; `RenderOutput.wait()` - called by
+    render_backward - completes it (`total_pairs`, the trimmed `gaussian_indices`) and raises PredictionMiss if the
+    predicted capacity was too small (the view must then be rendered again: the image is invalid)."""
     _torch_check(model.is_valid(), "GaussianModel is not valid")
     _torch_check(model.positions.is_cuda, "GaussianModel must be on CUDA device")
     n = model.num_gaussians()
@@ -424,6 +429,10 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, f
     srt = sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, camera.width,
                                    camera.height, want_keys=False)
     fwd = blend(srt)                                     # queued behind the sort; the host has not waited yet
+    if defer_count and isinstance(srt, PendingSort):
+        return RenderOutput(fwd.color, fwd.final_T, fwd.n_contrib, proj.means_2d, proj.depths, proj.cov_2d_inv,
+                            proj.radii, proj.rgb, proj.opacities_act, srt.gaussian_values_sorted, srt.tile_ranges,
+                            packed=proj.packed, total_pairs=-1, zeroed_accum=accum, pending=srt)
     if isinstance(srt, PendingSort):
         srt, valid = srt.finish()
         if not valid:                                    # prediction too small (e.g. right after densification)
@@ -454,6 +463,7 @@ def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: Ga
                               torch.zeros((0, 1), **f), torch.zeros_like(model.sh_coeffs),
                               torch.zeros((0, 2), **f))
     active_degree = min(int(settings.active_sh_degree), model.max_sh_degree())
+    render_out.wait()                                    # a deferred render: read the pair count now (may raise)
     # the accumulator render() had the forward blend clear is good for ONE backward
     zeroed, render_out.zeroed_accum = getattr(render_out, "zeroed_accum", None), None
     rb = rasterize_backward(dL_dcolor, render_out.means_2d, render_out.cov_2d_inv, render_out.rgb,

@@ -187,6 +187,25 @@ class RenderOutput:
     packed: Optional[torch.Tensor] = None       # scratch kept alive for render_backward
     total_pairs: int = 0
     zeroed_accum: Optional[torch.Tensor] = None # [N,16] accumulator already cleared by the forward blend (one backward)
+    pending: Optional[object] = None            # render(..., defer_count=True): the sort's pair count has not been read yet
+
+    def wait(self) -> "RenderOutput":
+        """Completes a render(..., defer_count=True): waits for the sort's pair count, trims `gaussian_indices` to it
+        and fills in `total_pairs`.  Raises PredictionMiss if the predicted capacity was too small - everything
+        computed from this output (the image included) is then invalid and the view must be rendered again."""
+        if self.pending is not None:
+            pending, self.pending = self.pending, None
+            srt, valid = pending.finish()
+            if not valid:
+                raise PredictionMiss("render(defer_count=True): the predicted pair capacity was too small; "
+                                     "render this view again (the next prediction is already corrected)")
+            self.gaussian_indices, self.total_pairs = srt.gaussian_values_sorted, srt.total_pairs
+        return self
+
+
+class PredictionMiss(RuntimeError):
+    """A deferred render ran on a pair capacity that turned out too small (first frames of a new view set, right
+    after a densification): its outputs are invalid.  Render again without defer_count (or simply again)."""
 
 
 @dataclass

@@ -651,3 +651,39 @@ def test_sort_is_memory_safe_on_inconsistent_tile_counts(pkg, orc, dev, mu_s):
     vals, tr = np_(srt.gaussian_values_sorted), np_(srt.tile_ranges)
     assert vals.shape[0] == total and vals.min() >= 0 and vals.max() < n
     assert tr.min() >= 0 and tr.max() <= total and np.all(tr[:, 1] >= tr[:, 0])
+
+
+def test_deferred_pair_count_render(pkg, orc, dev):
+    """render(..., defer_count=True) returns before the host has read the sort's pair count (a training loop queues
+    its loss kernels in that window); wait() / render_backward complete it.  Same image, indices and gradients as
+    the blocking render; a capacity that turns out too small raises PredictionMiss instead of handing out an
+    invalid frame, and the next render is right again."""
+    n, w, h, deg = 20000, 640, 360, 2
+    arrays, cam = _scene(pkg, n, w, h, deg, seed=31, mu_s=-3.9)
+    settings = pkg.RenderSettings(background=[0.1, 0.4, 0.2], active_sh_degree=deg)
+    model = pkg.scene.to_model(arrays, dev)
+    g = torch.from_numpy(pkg.scene.make_dl_dcolor(w, h, seed=32)).to(dev)
+    R = pkg.rasterizer
+    ref = pkg.render(model, cam, settings)                       # blocking; also seeds the prediction
+    ref_g = pkg.render_backward(g, ref, model, cam, settings)
+    out = pkg.render(model, cam, settings, defer_count=True)
+    assert out.pending is not None and out.total_pairs == -1
+    grads = pkg.render_backward(g, out, model, cam, settings)    # waits, trims, runs
+    assert out.pending is None and out.total_pairs == ref.total_pairs
+    assert torch.equal(out.gaussian_indices, ref.gaussian_indices) and torch.equal(out.color, ref.color)
+    for k in ("dL_dpositions", "dL_dsh_coeffs", "dL_dscales"):
+        a, b = getattr(ref_g, k), getattr(grads, k)
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), k
+    # a prediction that is too small
+    R._last_pairs[torch.device(dev)] = 50
+    R._held_capacity.pop(torch.device(dev), None)
+    margin = R.PREDICT_MARGIN
+    R.PREDICT_MARGIN = (1.0, 0)
+    try:
+        bad = pkg.render(model, cam, settings, defer_count=True)
+        with pytest.raises(pkg.PredictionMiss):
+            bad.wait()
+    finally:
+        R.PREDICT_MARGIN = margin
+    again = pkg.render(model, cam, settings, defer_count=True).wait()
+    assert again.total_pairs == ref.total_pairs and torch.equal(again.color, ref.color)
