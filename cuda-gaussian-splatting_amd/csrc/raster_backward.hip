@@ -383,6 +383,10 @@ __global__ void k_dbg_rcp(const float* __restrict__ in, float* __restrict__ out,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = __builtin_amdgcn_rcpf(in[i]);
 }
+__global__ void k_dbg_blend_exp(const float* __restrict__ q, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cugs_blend_exp_q(q[i]);
+}
 bool g_dev_backward_stats = false;
 }  // namespace
 bool cugs_dev_backward_stats() { return g_dev_backward_stats; }
@@ -394,6 +398,11 @@ extern "C" int cugsdbg_reduce9(const float* in, float* out, int* slots, void* st
 }
 extern "C" int cugsdbg_reduce9r16(const float* in, float* out, int* slots, void* stream) {
     hipLaunchKernelGGL(k_dbg_reduce9r16, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in, out, slots);
+    CUGS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cugsdbg_blend_exp_q(const float* q, float* out, int n, void* stream) {
+    hipLaunchKernelGGL(k_dbg_blend_exp, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), q, out, n);
     CUGS_LAUNCH_CHECK();
     return 0;
 }

@@ -82,3 +82,20 @@ def test_rcp_of_one_is_exactly_one(pkg, dev):
     o = out.cpu().numpy()
     assert o[0] == 1.0 and o[1] == 2.0 and o[2] == 0.5 and o[3] == 4.0      # powers of two are exact
     assert np.allclose(o[4:], 1.0 / x.cpu().numpy()[4:], rtol=3e-7)          # 1 ulp elsewhere
+
+
+def test_blend_exponential_has_the_oracles_bits(pkg, orc, dev):
+    """cugs_blend_exp_q is the one transcendental the blend DECISIONS depend on: the device version (v_med3, v_fma,
+    v_lshl_add_u32) must return the host version's bits for every input the kernels can feed it - the whole range of
+    the quadratic form, values around the clamp at q = 12, tiny, negative, denormal and huge ones."""
+    lib = _dev_lib(pkg)
+    rng = np.random.default_rng(7)
+    q = np.concatenate([rng.uniform(0.0, 12.5, 2_000_000), np.linspace(11.9, 12.1, 100_001),
+                        np.float32(2.0) ** -np.arange(0, 150, dtype=np.float32), -np.float32(2.0) ** -np.arange(0, 150, dtype=np.float32),
+                        [0.0, -0.0, 12.0, 1e9, 3e38, np.inf, 1e-45, -1e-45]]).astype(np.float32)
+    x = torch.from_numpy(q).to(dev)
+    out = torch.empty_like(x)
+    rc = lib.cugsdbg_blend_exp_q(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int(x.numel()), C.c_void_p(0))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), orc.blend_exp_q(q).view(np.uint32))
