@@ -18,6 +18,7 @@ from util import max_err_over_max, np_, oracle_backward, oracle_forward   # noqa
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    dense = len(sys.argv) > 3 and sys.argv[3] == "dense"      # larger, denser scenes: the sort's column route, long lists
     pkg, orc = ge.load_package(), ge.load_oracle()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
@@ -28,6 +29,10 @@ def main():
         h = int(rng.choice([1, 9, 16, 33, 96, 217, 360]))
         deg = int(rng.integers(0, 4))
         mu_s = float(rng.choice([-6.0, -4.6, -3.8, -3.0, -2.0, -0.5]))
+        if dense:
+            n = int(rng.choice([5000, 12000, 25000]))
+            w, h = [(640, 360), (1000, 400), (1280, 720), (517, 389)][int(rng.integers(0, 4))]
+            mu_s = float(rng.choice([-3.6, -3.2, -2.8]))
         view = int(rng.integers(0, 6))
         bg = tuple(float(x) for x in rng.random(3))
         scale_mod = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
@@ -59,7 +64,7 @@ def main():
             err = max_err_over_max(got, refb[name])
             worst = max(worst, err)
             assert err <= 1e-4, (tag, name, err)
-        if k % 20 == 0:
+        if k % (2 if dense else 20) == 0:
             print(tag, "ok; worst gradient error so far %.2e" % worst, flush=True)
     print(f"{cases} cases ok, worst gradient error {worst:.2e}")
 
