@@ -452,6 +452,11 @@ def main():
     g_host = pkg.scene.make_dl_dcolor(wl.width, wl.height, seed=pkg.scene.GRAD_SEED + rank)
     g = torch.from_numpy(g_host).to(dev)
     opt = pkg.FusedAdam(model) if use_adam else None
+    if opt is not None:
+        # Every launch and every byte of the optimizer step, with all learning rates at zero: Adam with eps = 1e-15
+        # takes lr-sized steps whatever the gradient, and on this synthetic gradient field that blows the splats up
+        # (config 4: 40 M -> 110 M pairs within 3000 steps) - the timed steps would not be the named workload.
+        opt.learning_rates_ = [0.0] * opt.kNumGroups
     c = pkg.sh_coeff_count(wl.sh_degree)
     # every rank knows every view's camera in this benchmark: no device-to-host read of the gathered centres
     all_centres = [pkg.scene.make_camera(wl.width, wl.height, view=r).camera_center().tolist() for r in range(world)]
@@ -587,6 +592,7 @@ def main():
             "config": {"workload": wl.name + (" fwd only" if forward_only else " fwd+bwd") + (" +adam" if use_adam else ""),
                        "n_gaussians": wl.n, "width": wl.width, "height": wl.height, "sh_degree": wl.sh_degree,
                        "pairs": int(pairs), "mu_s": wl.mu_s, "views_per_step": n_gpus,
+                       **({"adam_learning_rates": 0.0} if use_adam else {}),
                        "parallelism": f"dp{n_gpus}-views" + (f"+rccl-{exchange['mode']}" if launched else ""),
                        "exchange_calibration_ms": exchange["calibration_ms"]},
             "roofline": roofline, "frame_roofline": frame,
