@@ -231,11 +231,42 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_stats(int w, int h, Window 
     }
 }
 
+// The per-tile partial sums -> loss_out[0] = combined loss, [1] = L1 mean, [2] = mean SSIM, [3] = 1 - mean SSIM
+// (ssim_loss); one workgroup, fp64, fixed order (thread t takes tiles t, t + 256, ...; then a tree): deterministic.
+// s_acc: 2 x CUGS_BLOCK doubles of LDS.  Contains barriers: call with the whole workgroup.
+__device__ __forceinline__ void finalize_loss(const double* __restrict__ partials, int nblk, double count, float lambda,
+                                              float* __restrict__ out, double (*s_acc)[CUGS_BLOCK]) {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += CUGS_BLOCK) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+    s_acc[0][threadIdx.x] = a; s_acc[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int d = CUGS_BLOCK / 2; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            s_acc[0][threadIdx.x] += s_acc[0][threadIdx.x + d];
+            s_acc[1][threadIdx.x] += s_acc[1][threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double l1 = s_acc[0][0] / count, ss = s_acc[1][0] / count;
+        out[0] = (float)((1.0 - (double)lambda) * l1 + (double)lambda * (1.0 - ss));
+        out[1] = (float)l1;
+        out[2] = (float)ss;
+        out[3] = (float)(1.0 - ss);
+    }
+    __syncthreads();
+}
+
+// `partials` != nullptr: workgroup (0, 0) first reduces the loss sums of k_ssim_stats (finalize_loss, in the LDS the
+// tiles go to afterwards) - it starts first and is done long before the grid is, and the separate one-workgroup
+// launch (~10 us of kernel boundary and latency for 130 KB) disappears from the iteration.
 template <int RT>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_grad(int w, int h, Window win, float lambda,
                                                           const float* __restrict__ xr, const float* __restrict__ yt,
                                                           const float* __restrict__ d_m, const float* __restrict__ d_p,
-                                                          const float* __restrict__ d_r, float* __restrict__ dL_dx) {
+                                                          const float* __restrict__ d_r, float* __restrict__ dL_dx,
+                                                          const double* __restrict__ partials, int nblk, double count,
+                                                          float* __restrict__ loss_out) {
     constexpr int CW = LT * 3;
     constexpr bool ALIAS = RT > 0;                                       // as in k_ssim_stats
     constexpr int ET = ALIAS ? LT + 2 * RT : MAX_E;
@@ -243,6 +274,9 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_grad(int w, int h, Window w
     __shared__ float s_pool[ALIAS ? 3 * IN_F : 3 * IN_F + 3 * H_F];
     float* const s_a[3] = {s_pool, s_pool + IN_F, s_pool + 2 * IN_F};
     float* const s_hp = ALIAS ? s_pool : s_pool + 3 * IN_F;
+    static_assert(sizeof(s_pool) >= 2 * CUGS_BLOCK * sizeof(double), "finalize_loss borrows the tile pool");
+    if (partials && blockIdx.x == 0 && blockIdx.y == 0)
+        finalize_loss(partials, nblk, count, lambda, loss_out, reinterpret_cast<double (*)[CUGS_BLOCK]>(s_pool));
     const int R = RT > 0 ? RT : win.r, E = LT + 2 * R;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT;
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
@@ -343,27 +377,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_ssim_grad(int w, int h, Window w
     }
 }
 
-// loss_out[0] = combined loss, [1] = L1 mean, [2] = mean SSIM, [3] = 1 - mean SSIM (ssim_loss)
+// The same reduction as its own launch, for callers that want the loss without the gradient.
 __global__ __launch_bounds__(CUGS_BLOCK) void k_loss_finalize(const double* __restrict__ partials, int nblk, double count,
                                                                float lambda, float* __restrict__ out) {
     __shared__ double s_acc[2][CUGS_BLOCK];
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += CUGS_BLOCK) { a += partials[2 * i]; b += partials[2 * i + 1]; }
-    s_acc[0][threadIdx.x] = a; s_acc[1][threadIdx.x] = b;
-    __syncthreads();
-    for (int d = CUGS_BLOCK / 2; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) {
-            s_acc[0][threadIdx.x] += s_acc[0][threadIdx.x + d];
-            s_acc[1][threadIdx.x] += s_acc[1][threadIdx.x + d];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    const double l1 = s_acc[0][0] / count, ss = s_acc[1][0] / count;
-    out[0] = (float)((1.0 - (double)lambda) * l1 + (double)lambda * (1.0 - ss));
-    out[1] = (float)l1;
-    out[2] = (float)ss;
-    out[3] = (float)(1.0 - ss);
+    finalize_loss(partials, nblk, count, lambda, out, s_acc);
 }
 
 }  // namespace
@@ -412,15 +430,18 @@ extern "C" int cugs_combined_loss(int width, int height, const float* rendered, 
     else
         hipLaunchKernelGGL(k_ssim_stats<0>, grid, block, 0, st, width, height, win, rendered, target, d_m, d_p, d_r, ssim_map, sums);
     CUGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(CUGS_BLOCK), 0, st, sums, (int)tiles, (double)width * height * 3.0, lambda,
-                       loss_out);
-    CUGS_LAUNCH_CHECK();
-    if (dL_dcolor) {
-        if (win.r == 5)
-            hipLaunchKernelGGL(k_ssim_grad<5>, grid, block, 0, st, width, height, win, lambda, rendered, target, d_m, d_p, d_r, dL_dcolor);
-        else
-            hipLaunchKernelGGL(k_ssim_grad<0>, grid, block, 0, st, width, height, win, lambda, rendered, target, d_m, d_p, d_r, dL_dcolor);
+    const double count = (double)width * height * 3.0;
+    if (!dL_dcolor) {
+        hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(CUGS_BLOCK), 0, st, sums, (int)tiles, count, lambda, loss_out);
         CUGS_LAUNCH_CHECK();
+        return 0;
     }
+    if (win.r == 5)
+        hipLaunchKernelGGL(k_ssim_grad<5>, grid, block, 0, st, width, height, win, lambda, rendered, target, d_m, d_p, d_r,
+                           dL_dcolor, sums, (int)tiles, count, loss_out);
+    else
+        hipLaunchKernelGGL(k_ssim_grad<0>, grid, block, 0, st, width, height, win, lambda, rendered, target, d_m, d_p, d_r,
+                           dL_dcolor, sums, (int)tiles, count, loss_out);
+    CUGS_LAUNCH_CHECK();
     return 0;
 }
