@@ -323,11 +323,11 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         (void)hipEventDestroy(ev);
         TORCH_CHECK(ok, "hipEventSynchronize failed");
         const int64_t p = total.data_ptr<int64_t>()[0];
-        TORCH_CHECK(p >= 0 && p <= 2147483647ll, "pair count exceeds the reference's int indexing");
-        if (p <= cap) {
+        TORCH_CHECK(p >= -1 && p <= 2147483647ll, "pair count exceeds the reference's int indexing");
+        if (p >= 0 && p <= cap) {
             srt.total_pairs = static_cast<int>(p);
             srt.gaussian_values_sorted = srt.gaussian_values_sorted.slice(0, 0, p);
-        } else {                                            // prediction too small: exact path, blend again
+        } else {                                            // prediction too small (or -1: a depth outside the three-pass sort's range): exact path, blend again
             srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
             fwd = blend(srt);
         }

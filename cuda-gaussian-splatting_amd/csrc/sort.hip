@@ -10,7 +10,8 @@
 // How it is produced here (not the reference's schedule): a stable LSD sort by the full key is the
 // same permutation as (1) a stable sort of the N Gaussians by depth bits, (2) emitting each
 // Gaussian's pairs in that order, (3) a stable sort of the P pairs by tile id alone.  (1) moves
-// 8 B x N x 4 passes, (3) moves 8 B x P x ceil(log2(tiles)/8) passes (2 at 1080p) instead of
+// 8 B x N x 3 passes (9-bit digits on the 27-bit offset of the depth bits from the near plane; 4 passes of 8 bits on
+// the raw bits for views outside that range), (3) moves 8 B x P x ceil(log2(tiles)/8) passes (2 at 1080p) instead of
 // 12 B x P x 8 passes.  Every pass is the same three kernels: per-workgroup digit histogram,
 // per-digit row scan, stable scatter with wave64 ballot ranking.  All HBM-bound integer work.
 //
@@ -26,6 +27,15 @@
 namespace {
 
 constexpr int RADIX = 256;
+// The depth sort of views whose depths lie in [near plane, ~13 000) - every view the reference's projection can
+// produce in practice: it culls z <= 0.2 - runs THREE passes of 9 bits on the key's offset from the near plane's bit
+// pattern instead of four passes of 8 bits on the raw float bits: positive floats order like their bit patterns, and
+// [0.2, 13 107) spans 2^27 patterns.  A kernel boundary costs ~5 us on this part and a pass is three kernels.  The key
+// kernel checks the range of every Gaussian that emits pairs; a view outside it is reported through the pair count
+// (-1: "redo") and takes the four-pass route on the raw bits.
+constexpr int RADIX_DEPTH = 512, DEPTH_BITS = 9;
+constexpr uint32_t DEPTH_KEY_BASE = 0x3E4CCCCCu;  // float bits of 0.2f, minus one: offsets of visible splats start at 1, 0 = "sorts first"
+constexpr uint32_t DEPTH_KEY_SPAN = 1u << (3 * DEPTH_BITS);
 constexpr int IPT = 16;                           // items per thread
 constexpr int CHUNK_MIN = CUGS_BLOCK * IPT;       // 4096 items per workgroup: depth sort; sizes the histogram buffers
 #ifndef CUGS_PAIR_CHUNK_MULT
@@ -51,9 +61,9 @@ struct SortWsN {
     uint32_t* dkey[2];           // depth bits, ping-pong              [n]
     uint32_t* dval[2];           // Gaussian index, ping-pong          [n]
     int4* rect[2];               // {x0, y0, w | h << 16, tiles_touched} per Gaussian: [0] input order, [1] depth order
-    uint32_t* tot;               // [RADIX]
+    uint32_t* tot;               // [RADIX_DEPTH]
     uint32_t* blocksum;          // per FILL_CHUNK block pair counts   [nfill + 2]
-    uint32_t* hist;              // [RADIX][nblk_n] digit-major
+    uint32_t* hist;              // [RADIX_DEPTH][nblk_n] digit-major
     uint32_t* colhist;           // [RADIX][ncol] pairs per (tile column, COL_CHUNK block), as counted
     uint32_t* colscan;           // ... and scanned along each column's row
     size_t bytes;
@@ -81,9 +91,9 @@ SortWsN carve_n(void* base, int64_t n) {
     for (int i = 0; i < 2; ++i) w.dkey[i] = c.take<uint32_t>((size_t)n);
     for (int i = 0; i < 2; ++i) w.dval[i] = c.take<uint32_t>((size_t)n);
     for (int i = 0; i < 2; ++i) w.rect[i] = c.take<int4>((size_t)n);
-    w.tot = c.take<uint32_t>(RADIX);
+    w.tot = c.take<uint32_t>(RADIX_DEPTH);
     w.blocksum = c.take<uint32_t>((size_t)nblocks_for(n, FILL_CHUNK) + 2);
-    w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, CHUNK_MIN) + 1));
+    w.hist = c.take<uint32_t>((size_t)RADIX_DEPTH * (nblocks_for(n, CHUNK_MIN) + 1));
     w.colhist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
     w.colscan = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
     w.bytes = c.off;
@@ -147,7 +157,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_depth_keys_rect(uint32_t n, cons
                                                                 const int32_t* __restrict__ tiles, int img_w,
                                                                 int img_h, int ntx, int nty,
                                                                 uint32_t* __restrict__ keys,
-                                                                int4* __restrict__ rect) {
+                                                                int4* __restrict__ rect,
+                                                                uint32_t* __restrict__ range_flag) {
     const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t key = __float_as_uint(depths[i]);
@@ -160,6 +171,12 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_depth_keys_rect(uint32_t n, cons
             if (tr.x1 > tr.x0 && tr.y1 > tr.y0) { x0 = tr.x0; y0 = tr.y0; w = tr.x1 - tr.x0; h = tr.y1 - tr.y0; }
         }
         if (w == 0) key = 0u;                                            // fills nothing: Q12
+    }
+    if (range_flag) {                                                    // three-pass route: offset from the near plane
+        const uint32_t off = key - DEPTH_KEY_BASE;                       // wraps for keys below the base
+        const bool emits = t > 0 && w > 0;
+        if (emits && !(off >= 1u && off < DEPTH_KEY_SPAN)) atomicOr(range_flag, 1u);
+        key = emits ? min(off, DEPTH_KEY_SPAN - 1u) : 0u;                // a Gaussian without pairs may stand anywhere
     }
     keys[i] = key;
     rect[i] = make_int4(x0, y0, w | (h << 16), t > 0 ? t : 0);
@@ -176,7 +193,7 @@ __device__ __forceinline__ uint32_t live_count(uint32_t count, const unsigned lo
 
 // ctl: when given, block 0 hands the Q12 counter k_fill_pairs has finished adding to (ctl[0]) over to
 // k_tile_ranges (ctl[1]) and re-arms it, so that cugs_sort_pairs may be repeated on one count.
-template <typename K, int NT, int CHUNK>
+template <typename K, int NT, int CHUNK, int RDX = RADIX>
 __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, uint32_t count_or_cap,
                                                    const unsigned long long* __restrict__ dev_count, int shift,
                                                    uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
@@ -185,8 +202,9 @@ __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, u
     constexpr int PER = CHUNK / NT;                           // consecutive keys per thread (order is irrelevant here)
     constexpr int NWORDS = PER * (int)sizeof(K) / 4;          // ... fetched as dwords in 16- or 8-byte loads
     static_assert(NWORDS >= 2 && NWORDS * 4 == PER * (int)sizeof(K), "whole 8-byte loads per thread");
-    __shared__ uint32_t s_cnt[RADIX];
-    if (threadIdx.x < RADIX) s_cnt[threadIdx.x] = 0;
+    static_assert(NT >= RDX, "one thread per digit");
+    __shared__ uint32_t s_cnt[RDX];
+    if (threadIdx.x < RDX) s_cnt[threadIdx.x] = 0;
     if (ctl && blockIdx.x == 0 && threadIdx.x == 0) { ctl[1] = ctl[0]; ctl[0] = 0u; }
     __syncthreads();
     const uint32_t bbase = blockIdx.x * CHUNK;
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, u
             atomicAdd(&s_cnt[((uint32_t)keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < RADIX) hist[threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
+    if (threadIdx.x < RDX) hist[threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
 }
 
 // Block d: exclusive scan of row d of hist into `out` (may be hist itself); tot[d] = row sum.
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(const uint32_t* 
 // array.  NB: digit width (the match-any needs one ballot per digit bit).  NT: threads per workgroup -
 // 256 for the pair-level passes (thousands of workgroups), 1024 for the depth sort, whose 4096-item
 // chunks are too few to fill the chip with 4 waves each.
-template <typename K, bool IOTA, int NB, int NT, bool ARANK, int CHUNK>
+template <typename K, bool IOTA, int NB, int NT, bool ARANK, int CHUNK, int RDX = RADIX>
 __global__ __launch_bounds__(NT) void k_radix_scatter(
     const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count_or_cap,
     const unsigned long long* __restrict__ dev_count, int shift, uint32_t mask_rt, const uint32_t* __restrict__ hist,
@@ -270,9 +288,10 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
     constexpr int NW = NT / CUGS_WAVE;                    // waves
     constexpr int PER = CHUNK / NT;                       // items per thread
     constexpr int SLICE = CUGS_WAVE * PER;                // contiguous items per wave
-    __shared__ uint32_t s_lbase[NW][RADIX];    // per (wave, digit): count, then running LOCAL position
-    __shared__ uint32_t s_lstart[RADIX];       // first local position of digit d
-    __shared__ uint32_t s_gbase[RADIX];        // first global position of this workgroup's digit-d run
+    static_assert(NT >= RDX && (1 << NB) <= RDX, "one thread per digit");
+    __shared__ uint32_t s_lbase[NW][RDX];      // per (wave, digit): count, then running LOCAL position
+    __shared__ uint32_t s_lstart[RDX];         // first local position of digit d
+    __shared__ uint32_t s_gbase[RDX];          // first global position of this workgroup's digit-d run
     __shared__ K s_key[CHUNK];
     __shared__ uint32_t s_val[CHUNK];
     __shared__ uint32_t s_tmp[NW];
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
     const uint32_t wbase = bbase + wave * SLICE;
     const uint32_t count_blk = min((uint32_t)CHUNK, count - bbase);
 
-    for (uint32_t e = tid; e < NW * RADIX; e += NT) (&s_lbase[0][0])[e] = 0;
+    for (uint32_t e = tid; e < NW * RDX; e += NT) (&s_lbase[0][0])[e] = 0;
     __syncthreads();
 
     uint32_t k[PER], v[PER];
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
     __syncthreads();
 
     {   // digit d = tid (threads beyond the radix only take part in the barriers)
-        const bool dig = tid < RADIX;
+        const bool dig = tid < RDX;
         uint32_t cnt = 0;
         if (dig) {
 #pragma unroll
@@ -412,11 +431,15 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_blocksums(uint32_t n,
 // Single workgroup: exclusive scan of blocksum[0..nb) in place; *total = the 64-bit grand total =
 // sum(tiles_touched), the reference's cumsum[-1].item() (sorting.cu:145-146).  16 consecutive entries per
 // thread, so 16384 entries cost two barriers.  Also arms the Q12 counter (ctl[0] = 0).
+// range_flag (three-pass depth sort): non-zero = some depth key lay outside the range that route covers, the order
+// is not valid: the device-side total becomes 0 (every pair-level kernel then does nothing), the host-visible one
+// (total[1], total_mapped) -1, and the flag is re-armed.
 constexpr int SCAN_NT = 1024;                     // one workgroup, on the critical path of the pair count: as wide as it gets
 __global__ __launch_bounds__(SCAN_NT) void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb,
                                                             unsigned long long* __restrict__ total,
                                                             uint32_t* __restrict__ ctl,
-                                                            unsigned long long* __restrict__ total_mapped) {
+                                                            unsigned long long* __restrict__ total_mapped,
+                                                            uint32_t* __restrict__ range_flag) {
     __shared__ uint32_t s_tmp[SCAN_NT / CUGS_WAVE];
     constexpr int PER = 16;
     unsigned long long carry = 0;
@@ -435,11 +458,15 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan_blocksums(uint32_t* __restrict
         carry += chunk_total;
     }
     if (threadIdx.x == 0) {
-        *total = carry;
+        bool bad = false;
+        if (range_flag) { bad = *range_flag != 0u; *range_flag = 0u; }
+        const unsigned long long host_total = bad ? ~0ull : carry;
+        total[0] = bad ? 0ull : carry;
+        total[1] = host_total;
         ctl[0] = 0u;
         // the caller's pinned host variable, when it is mapped into the device's address space: one store here
         // instead of a copy kernel on the critical path of the predicted-capacity sort (~5 us)
-        if (total_mapped) __hip_atomic_store(total_mapped, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (total_mapped) __hip_atomic_store(total_mapped, host_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -834,17 +861,23 @@ constexpr int rank_mode() { return 0; }            // ballot ranking: defined by
 #endif
 
 
-template <typename K, bool IOTA, int NT, int CHUNK>
+template <typename K, bool IOTA, int NT, int CHUNK, int RDX = RADIX>
 int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned long long* dev_count, int shift, int bits,
                uint32_t* hist, uint32_t* tot, K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st) {
     const uint32_t nblk = nblocks_for(count, CHUNK);
     if (!hist_done) {
-        hipLaunchKernelGGL((k_radix_hist<K, NT, CHUNK>), dim3(nblk), dim3(NT), 0, st, kin, count, dev_count, shift,
+        hipLaunchKernelGGL((k_radix_hist<K, NT, CHUNK, RDX>), dim3(nblk), dim3(NT), 0, st, kin, count, dev_count, shift,
                            (1u << bits) - 1u, hist, nblk, ctl);
         CUGS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, hist, hist, nblk, tot);
+    hipLaunchKernelGGL(k_radix_scan_rows, dim3(RDX), dim3(CUGS_BLOCK), 0, st, hist, hist, nblk, tot);
     CUGS_LAUNCH_CHECK();
+    if constexpr (RDX == RADIX_DEPTH) {                    // the 9-bit passes of the depth sort: ballot ranking only
+        hipLaunchKernelGGL((k_radix_scatter<K, IOTA, DEPTH_BITS, NT, false, CHUNK, RDX>), dim3(nblk), dim3(NT), 0, st, kin, vin, count,
+                           dev_count, shift, 0u, hist, tot, nblk, kout, vout);
+        CUGS_LAUNCH_CHECK();
+        return 0;
+    }
 #ifdef CUGS_DEV
     if (rank_mode() == 1) {               // digit width only matters to the ballot ranking: one instantiation
         hipLaunchKernelGGL((k_radix_scatter<K, IOTA, 8, NT, true, CHUNK>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count,
@@ -947,25 +980,39 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
 }
 
 // Steps (1)-(2a): everything that does not depend on the pair count.  Queued, never blocks.
+// three_pass: the depth sort on 27-bit offsets from the near plane (see RADIX_DEPTH); if a depth key turns out to lie
+// outside that range the totals say so (k_scan_blocksums) and the caller runs this again with three_pass = false.
 int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const float* depths, const int32_t* radii,
                 const int32_t* tiles_touched, int width, int height, int ntx, int nty, hipStream_t st,
-                unsigned long long* total_mapped = nullptr) {
-    // (1) stable sort of the Gaussians by depth bits (positive floats order as unsigned ints)
-    hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
-                       means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1], ws.rect[0]);
-    CUGS_LAUNCH_CHECK();
+                unsigned long long* total_mapped = nullptr, bool three_pass = true) {
+    uint32_t* range_flag = reinterpret_cast<uint32_t*>(ws.total) + 6;
     int rc;
-    if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN>(ws.dkey[1], nullptr, un, nullptr, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
-    if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
-    if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[1], ws.dval[1], un, nullptr, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
-    if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+    if (three_pass) {
+        // (1) stable sort of the Gaussians by depth: keys -> dkey[0], three passes [0] -> [1] -> [0] -> [1]
+        hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
+                           means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[0], ws.rect[0], range_flag);
+        CUGS_LAUNCH_CHECK();
+        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+    } else {
+        // (1) the general route: four passes of 8 bits on the raw depth bits (positive floats order as unsigned ints)
+        hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
+                           means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1], ws.rect[0],
+                           static_cast<uint32_t*>(nullptr));
+        CUGS_LAUNCH_CHECK();
+        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN>(ws.dkey[1], nullptr, un, nullptr, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[1], ws.dval[1], un, nullptr, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+    }
     // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
     hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
                        ws.blocksum);
     CUGS_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_NT), 0, st, ws.blocksum, nfill, ws.total,
-                       reinterpret_cast<uint32_t*>(ws.total) + 4, total_mapped);
+                       reinterpret_cast<uint32_t*>(ws.total) + 4, total_mapped, three_pass ? range_flag : static_cast<uint32_t*>(nullptr));
     CUGS_LAUNCH_CHECK();
     return 0;
 }
@@ -1020,8 +1067,16 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const flo
     }
 #endif
     // straight into the caller's variable: if that is pinned host memory the copy is one DMA, no staging
-    CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     CUGS_RETURN_IF_HIP(hipStreamSynchronize(st));
+    if (*total_pairs_host == -1) {
+        // a depth key outside the range of the three-pass depth sort (a view with splats nearer than the near plane
+        // or farther than ~13 000 units): the general four-pass route, once more
+        rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st, nullptr, false);
+        if (rc) return rc;
+        CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        CUGS_RETURN_IF_HIP(hipStreamSynchronize(st));
+    }
 #ifdef CUGS_DEV
     if (probing) g_rank_mode.store(violations == 0 ? 1 : 0, std::memory_order_relaxed);
 #endif
@@ -1101,7 +1156,7 @@ extern "C" int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const floa
     int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st, mapped);
     if (rc) return rc;
     if (!mapped)
-        CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     if (capacity == 0) {                                          // valid iff the total turns out to be 0
         CUGS_RETURN_IF_HIP(hipMemsetAsync(tile_ranges, 0, sizeof(int32_t) * 2 * (size_t)tiles, st));
         return 0;

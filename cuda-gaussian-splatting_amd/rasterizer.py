@@ -223,6 +223,8 @@ class PendingSort:
         self._event.synchronize()
         p = int(self._total[0])
         means_2d, depths, radii, tiles, img_w, img_h, want_keys = self._args
+        if p == -1:      # a depth outside the range of the three-pass depth sort: the general route decides
+            return sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys), False
         _torch_check(0 <= p <= 2147483647, "pair count exceeds the reference's int indexing")
         prev = _last_pairs.get(means_2d.device, 0)
         _last_pairs[means_2d.device] = p if p > self.capacity else max(p, int(prev * 0.97))

@@ -114,8 +114,10 @@ int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* means_2d, const
  * (cugs_sort_pair_workspace_bytes(capacity)), keys_sorted and values_sorted for it; the pair-level kernels take
  * the live count from device memory.  The total is copied to *total_pairs_host asynchronously (pinned host
  * memory recommended); once the stream has completed, the outputs are valid iff
- * 0 <= *total_pairs_host <= capacity - otherwise call cugs_sort_pairs with the now known count (the N-level
- * workspace still holds the depth order).  Never blocks. */
+ * 0 <= *total_pairs_host <= capacity.  Otherwise: a count above the capacity -> call cugs_sort_pairs with the now
+ * known count (the N-level workspace still holds the depth order); -1 -> some splat's depth lies outside
+ * [0.2, ~13 000), the range the three-pass depth ordering of this entry point covers: call cugs_sort_count_pairs
+ * (which then takes the general route) and cugs_sort_pairs.  Never blocks. */
 int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
                               const int32_t* radii, const int32_t* tiles_touched, int width, int height,
                               void* workspace, size_t workspace_bytes, void* pair_workspace,

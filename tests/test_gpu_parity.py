@@ -687,3 +687,34 @@ def test_deferred_pair_count_render(pkg, orc, dev):
         R.PREDICT_MARGIN = margin
     again = pkg.render(model, cam, settings, defer_count=True).wait()
     assert again.total_pairs == ref.total_pairs and torch.equal(again.color, ref.color)
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.02, 5000.0])
+def test_depth_sort_routes(pkg, orc, dev, scale):
+    """The depth ordering runs three 9-bit passes on the key's offset from the near plane when every splat that emits
+    pairs has its depth in [0.2, ~13 000), and falls back to four 8-bit passes on the raw float bits otherwise -
+    decided on the device, reported through the pair count (-1).  Depths scaled below the near plane and beyond the
+    range must come out in the oracle's order just the same, through the blocking and the predicted entry points."""
+    n, w, h = 30000, 640, 360
+    arrays, cam = _scene(pkg, n, w, h, 0, seed=41, mu_s=-4.0)
+    ref = oracle_forward(orc, arrays, cam, degree=0)
+    depths = (ref["depths"] * np.float32(scale)).astype(np.float32)
+    srt_ref = orc.sort(ref["means_2d"], depths, ref["radii"], ref["tiles_touched"], w, h)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = (t(ref["means_2d"]), t(depths), t(ref["radii"]), t(ref["tiles_touched"]), w, h)
+    R = pkg.rasterizer
+    srt = pkg.sort_gaussians(*args)
+    R._last_pairs[torch.device(dev)] = srt.total_pairs
+    R._held_capacity.pop(torch.device(dev), None)
+    try:
+        pend = R.sort_gaussians_predicted(*args, want_keys=True)
+        srt2, valid = pend.finish()
+    finally:
+        R._last_pairs.pop(torch.device(dev), None)
+    in_range = depths[ref["tiles_touched"] > 0]
+    assert valid == bool(in_range.min() > 0.2 and in_range.max() < 13000.0)
+    for out in (srt, srt2):
+        assert out.total_pairs == srt_ref["total_pairs"]
+        assert np.array_equal(np_(out.gaussian_keys_sorted).view(np.uint64), srt_ref["keys"])
+        assert np.array_equal(np_(out.gaussian_values_sorted), srt_ref["values"])
+        assert np.array_equal(np_(out.tile_ranges), srt_ref["tile_ranges"])
