@@ -268,7 +268,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(const uint32_t* 
 }
 
 // Stable scatter.  Ranking: each wave owns a contiguous 1024-item slice and walks it in rounds of
-// 64; in a round the lanes holding the same digit find each other with 8 ballots (match-any), the
+// 64; in a round the lanes holding the same digit find each other with one ballot per digit bit (match-any), the
 // rank is the popcount below the lane, and the group's highest lane advances the wave's running
 // base in LDS.  The (key, value) pairs are first placed at their position in the workgroup's LOCALLY
 // sorted order in LDS and then streamed out, so that consecutive lanes write consecutive global
@@ -1036,7 +1036,7 @@ extern "C" size_t cugs_sort_pair_workspace_bytes(int64_t total_pairs) {
 }
 
 // Everything that does not depend on the pair count runs BEFORE the blocking read-back, so the
-// device is busy (depth keys, the 4-pass depth sort, per-block pair sums and their scan) while the
+// device is busy (depth keys, the depth sort, per-block pair sums and their scan) while the
 // host waits for the 8-byte total - the reference idles on cumsum[-1].item() instead (sorting.cu:146).
 extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const float* depths,
                                      const int32_t* radii, const int32_t* tiles_touched, int width,
