@@ -54,17 +54,17 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fused_adam_groups(AdamGroups G, 
         if (G.vec4[gi]) {
             const int64_t n4 = G.n[gi] >> 2;
             if (i < n4) {
-                float4 p = reinterpret_cast<float4*>(P)[i];
-                const float4 g = reinterpret_cast<const float4*>(Gr)[i];
-                float4 m = reinterpret_cast<float4*>(M)[i];
-                float4 v = reinterpret_cast<float4*>(V)[i];
+                float4 p = cugs_ldnt(reinterpret_cast<float4*>(P) + i);             // every stream here is touched once
+                const float4 g = cugs_ldnt(reinterpret_cast<const float4*>(Gr) + i);
+                float4 m = cugs_ldnt(reinterpret_cast<float4*>(M) + i);
+                float4 v = cugs_ldnt(reinterpret_cast<float4*>(V) + i);
                 adam_elem(p.x, g.x, m.x, v.x, lr, h);
                 adam_elem(p.y, g.y, m.y, v.y, lr, h);
                 adam_elem(p.z, g.z, m.z, v.z, lr, h);
                 adam_elem(p.w, g.w, m.w, v.w, lr, h);
-                reinterpret_cast<float4*>(P)[i] = p;
-                reinterpret_cast<float4*>(M)[i] = m;
-                reinterpret_cast<float4*>(V)[i] = v;
+                cugs_stnt(reinterpret_cast<float4*>(P) + i, p);
+                cugs_stnt(reinterpret_cast<float4*>(M) + i, m);
+                cugs_stnt(reinterpret_cast<float4*>(V) + i, v);
             } else {                                   // scalar tail: items n4 .. n4 + (n & 3)
                 const int64_t e = (n4 << 2) + (i - n4);
                 adam_elem(P[e], Gr[e], M[e], V[e], lr, h);

@@ -95,7 +95,7 @@ __device__ __forceinline__ void store_sh_rows(float* __restrict__ dst_base, int6
                 vals[k] = s_sh[row * LROW + col];
                 if (++col == ROW) { col = 0; ++row; }
             }
-            dst4[e4] = make_float4(vals[0], vals[1], vals[2], vals[3]);
+            cugs_stnt(dst4 + e4, make_float4(vals[0], vals[1], vals[2], vals[3]));
         }
         for (int e = (total4 << 2) + threadIdx.x; e < total; e += CUGS_BLOCK) {
             int row = e / ROW, col = e - row * ROW;
@@ -138,7 +138,8 @@ __device__ __forceinline__ void adam_sh_rows(float* __restrict__ param, float* _
     if (ALIGNED) {
         const int total4 = total >> 2;
         for (int e4 = threadIdx.x; e4 < total4; e4 += CUGS_BLOCK) {
-            float4 pp = reinterpret_cast<float4*>(P)[e4], mm = reinterpret_cast<float4*>(M)[e4], vv = reinterpret_cast<float4*>(V)[e4];
+            float4 pp = cugs_ldnt(reinterpret_cast<float4*>(P) + e4), mm = cugs_ldnt(reinterpret_cast<float4*>(M) + e4),
+                   vv = cugs_ldnt(reinterpret_cast<float4*>(V) + e4);             // streamed: read and written once
             int e = e4 * 4, row = e / ROW, col = e - row * ROW;
             float g[4];
 #pragma unroll
@@ -148,7 +149,8 @@ __device__ __forceinline__ void adam_sh_rows(float* __restrict__ param, float* _
             }
             adam_update(pp.x, g[0], mm.x, vv.x, lr, h); adam_update(pp.y, g[1], mm.y, vv.y, lr, h);
             adam_update(pp.z, g[2], mm.z, vv.z, lr, h); adam_update(pp.w, g[3], mm.w, vv.w, lr, h);
-            reinterpret_cast<float4*>(P)[e4] = pp; reinterpret_cast<float4*>(M)[e4] = mm; reinterpret_cast<float4*>(V)[e4] = vv;
+            cugs_stnt(reinterpret_cast<float4*>(P) + e4, pp); cugs_stnt(reinterpret_cast<float4*>(M) + e4, mm);
+            cugs_stnt(reinterpret_cast<float4*>(V) + e4, vv);
         }
         done = total4 << 2;
     }
@@ -266,6 +268,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     const int64_t idx = base + threadIdx.x;
     const bool live = idx < n;
     const int num_active = active_count(degree);
+    // parameters are streamed (non-temporal) unless the fused optimizer step reads them again further down
+    auto ldp = [](const float* q_) { return ADAM ? *q_ : cugs_ldnt(q_); };
 
     const bool gate_from_sh = (p.rgb_clamped == nullptr);      // kernel-uniform
     if (gate_from_sh) {
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     GradMoments mom{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};            // grad_accum rows carry moments (raster_backward.hip)
     const bool from_rows = (p.grad_accum != nullptr);         // kernel-uniform
     if (live) {
-        pos = V3{p.positions[idx * 3 + 0], p.positions[idx * 3 + 1], p.positions[idx * 3 + 2]};
+        pos = V3{ldp(p.positions + idx * 3 + 0), ldp(p.positions + idx * 3 + 1), ldp(p.positions + idx * 3 + 2)};
         float g_rgb[3];
         if (from_rows) {
             const float4* row = reinterpret_cast<const float4*>(p.grad_accum + idx * CUGS_GRAD_STRIDE);
@@ -327,9 +331,10 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     if (p.radii[idx] > 0) {                                    // projection_backward.cu:48
         const M3 W = view_rotation(cam);
         const V3 t = to_camera(cam, W, pos);
-        const V3 s{cugs_expf(p.scales[idx * 3 + 0] + cam.log_mod), cugs_expf(p.scales[idx * 3 + 1] + cam.log_mod),
-                   cugs_expf(p.scales[idx * 3 + 2] + cam.log_mod)};
-        const float4 q = ALIGNED ? reinterpret_cast<const float4*>(p.rotations)[idx]
+        const V3 s{cugs_expf(ldp(p.scales + idx * 3 + 0) + cam.log_mod), cugs_expf(ldp(p.scales + idx * 3 + 1) + cam.log_mod),
+                   cugs_expf(ldp(p.scales + idx * 3 + 2) + cam.log_mod)};
+        const float4 q = ALIGNED ? (ADAM ? reinterpret_cast<const float4*>(p.rotations)[idx]
+                                         : cugs_ldnt(reinterpret_cast<const float4*>(p.rotations) + idx))
                                  : make_float4(p.rotations[idx * 4 + 0], p.rotations[idx * 4 + 1],
                                                p.rotations[idx * 4 + 2], p.rotations[idx * 4 + 3]);
         const QuatRot qr = rotation_of(q.x, q.y, q.z, q.w);
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
             d_pos.y = W.m01 * dt.x + W.m11 * dt.y + W.m21 * dt.z;
             d_pos.z = W.m02 * dt.x + W.m12 * dt.y + W.m22 * dt.z;
 
-            const float sig = cugs_sigmoidf(p.opacities[idx]);
+            const float sig = cugs_sigmoidf(ldp(p.opacities + idx));
             d_logit = g_opa * sig * (1.0f - sig);
         }
     }
@@ -397,11 +402,12 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
             p.w_rot[idx * 4 + k] = w; adam.m[4][idx * 4 + k] = m; adam.v[4][idx * 4 + k] = v;
         }
     } else {
-        p.d_pos[idx * 3 + 0] = d_pos.x; p.d_pos[idx * 3 + 1] = d_pos.y; p.d_pos[idx * 3 + 2] = d_pos.z;
-        if (ALIGNED) reinterpret_cast<float4*>(p.d_rot)[idx] = d_q;
+        // the gradients are next read by the optimizer (or the exchange), a frame's worth of traffic later
+        cugs_stnt(p.d_pos + idx * 3 + 0, d_pos.x); cugs_stnt(p.d_pos + idx * 3 + 1, d_pos.y); cugs_stnt(p.d_pos + idx * 3 + 2, d_pos.z);
+        if (ALIGNED) cugs_stnt(reinterpret_cast<float4*>(p.d_rot) + idx, d_q);
         else { p.d_rot[idx * 4 + 0] = d_q.x; p.d_rot[idx * 4 + 1] = d_q.y; p.d_rot[idx * 4 + 2] = d_q.z; p.d_rot[idx * 4 + 3] = d_q.w; }
-        p.d_scl[idx * 3 + 0] = d_log.x; p.d_scl[idx * 3 + 1] = d_log.y; p.d_scl[idx * 3 + 2] = d_log.z;
-        p.d_opa[idx] = d_logit;
+        cugs_stnt(p.d_scl + idx * 3 + 0, d_log.x); cugs_stnt(p.d_scl + idx * 3 + 1, d_log.y); cugs_stnt(p.d_scl + idx * 3 + 2, d_log.z);
+        cugs_stnt(p.d_opa + idx, d_logit);
     }
     if (p.d_means_out) { p.d_means_out[idx * 2 + 0] = g_mx; p.d_means_out[idx * 2 + 1] = g_my; }
 }

@@ -37,7 +37,7 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ sh, int6
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int e4 = tid + i * CUGS_BLOCK;
-            v[i] = (e4 < TOTAL4) ? src4[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[i] = (e4 < TOTAL4) ? cugs_ldnt(src4 + e4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -57,7 +57,7 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ sh, int6
         const int total4 = total >> 2;
         const float4* src4 = reinterpret_cast<const float4*>(src);
         for (int e4 = tid; e4 < total4; e4 += CUGS_BLOCK) {
-            float4 v = src4[e4];
+            float4 v = cugs_ldnt(src4 + e4);
             int e = e4 * 4;
             int row = e / ROW, col = e - row * ROW;
             float vals[4] = {v.x, v.y, v.z, v.w};
@@ -100,10 +100,10 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
     const int64_t idx = base + threadIdx.x;
     const bool live = idx < n;
     const int64_t ld = live ? idx : (n - 1);
-    const V3 pos{p.positions[ld * 3 + 0], p.positions[ld * 3 + 1], p.positions[ld * 3 + 2]};
-    const float in_opa = p.opacities[ld];
-    const float in_s0 = p.scales[ld * 3 + 0], in_s1 = p.scales[ld * 3 + 1], in_s2 = p.scales[ld * 3 + 2];
-    const float4 q = ALIGNED ? reinterpret_cast<const float4*>(p.rotations)[ld]
+    const V3 pos{cugs_ldnt(p.positions + ld * 3 + 0), cugs_ldnt(p.positions + ld * 3 + 1), cugs_ldnt(p.positions + ld * 3 + 2)};
+    const float in_opa = cugs_ldnt(p.opacities + ld);
+    const float in_s0 = cugs_ldnt(p.scales + ld * 3 + 0), in_s1 = cugs_ldnt(p.scales + ld * 3 + 1), in_s2 = cugs_ldnt(p.scales + ld * 3 + 2);
+    const float4 q = ALIGNED ? cugs_ldnt(reinterpret_cast<const float4*>(p.rotations) + ld)
                              : make_float4(p.rotations[ld * 4 + 0], p.rotations[ld * 4 + 1],
                                            p.rotations[ld * 4 + 2], p.rotations[ld * 4 + 3]);
     stage_sh_rows<C, ALIGNED>(p.sh, base, count, s_sh);
