@@ -308,8 +308,9 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
     for (int r = 0; r < PER; ++r) {
         uint32_t i = wbase + r * CUGS_WAVE + lane;
         bool ok = i < count;
-        k[r] = ok ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
-        v[r] = ok ? (IOTA ? i : vals_in[i]) : 0u;
+        // last use of this pass's input: streamed, so that it does not evict the output being written for the next pass
+        k[r] = ok ? (uint32_t)__builtin_nontemporal_load(keys_in + i) : 0xFFFFFFFFu;
+        v[r] = ok ? (IOTA ? i : __builtin_nontemporal_load(vals_in + i)) : 0u;
         if (ok) atomicAdd(&s_lbase[wave][(k[r] >> shift) & mask], 1u);
     }
     __syncthreads();
@@ -499,8 +500,9 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     uint32_t g = 0, t = 0;
     int x0 = 0, y0 = 0, w = 0, real = 0;          // real = pairs the reference's loops would write
     if (i < n) {
-        g = order[i];
-        const int4 r = rect_sorted[i];
+        g = __builtin_nontemporal_load(order + i);                     // last use of both streams
+        typedef int v4i_ __attribute__((ext_vector_type(4)));
+        const v4i_ r = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(rect_sorted) + i);
         t = (uint32_t)r.w;
         x0 = r.x; y0 = r.y; w = r.z & 0xFFFF;
         real = w * (r.z >> 16);
