@@ -29,7 +29,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
     if (zero_buf) {
         const uint32_t per = (zero_vec4 + gridDim.x - 1) / gridDim.x;
         const uint32_t lo = blockIdx.x * per, hi = min(zero_vec4, lo + per);
-        for (uint32_t e = lo + threadIdx.x; e < hi; e += CUGS_BLOCK) zero_buf[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t e = lo + threadIdx.x; e < hi; e += CUGS_BLOCK) cugs_stnt(zero_buf + e, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     }
 
     const unsigned tile = cugs_xcd_remap(blockIdx.x, (unsigned)geo.ntiles);
