@@ -315,6 +315,41 @@ def test_rasterize_backward_stage_parity(pkg, orc, dev):
     assert not np_(rb.dL_drgb)[untouched].any()
 
 
+def test_blend_with_rows_beyond_32bit_byte_offsets(pkg, orc, dev):
+    """More than 2^26 Gaussians: the accumulator is larger than 4 GiB, so the scatter takes 64-bit addresses
+    (k_raster_backward<.., WIDE = true>), and the record gathers of both blend kernels index past 2^31 bytes.
+    A small scene placed at rows 2^26 .. 2^26 + n of otherwise empty tables must give the small scene's own
+    image (bit for bit) and gradients."""
+    w, h, n = 160, 120, 3000
+    base = (1 << 26) + 5
+    big = base + n
+    arrays, cam = _scene(pkg, n, w, h, 0, seed=5, mu_s=-3.3)
+    bg = (0.2, 0.1, 0.0)
+    ref = oracle_forward(orc, arrays, cam, degree=0, bg=bg)
+    g = pkg.scene.make_dl_dcolor(w, h)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def table(a):
+        full = torch.zeros((big,) + a.shape[1:], dtype=torch.float32, device=dev)
+        full[base:] = t(a)
+        return full
+    means, cov, rgb, opa = (table(ref[k]) for k in ("means_2d", "cov_2d_inv", "rgb", "opacities_act"))
+    idx = t(ref["values"]) + base
+    ranges = t(ref["tile_ranges"])
+    fwd = pkg.rasterize_forward(means, cov, rgb, opa, ranges, idx, w, h, bg)
+    assert np.array_equal(np_(fwd.color), ref["color"])
+    assert np.array_equal(np_(fwd.n_contrib), ref["n_contrib"])
+    rb = pkg.rasterize_backward(t(g), means, cov, rgb, opa, ranges, idx, fwd.final_T, fwd.n_contrib, w, h, bg, big)
+    want = orc.rasterize_backward(w, h, bg, ref["tile_ranges"], ref["values"], ref["means_2d"], ref["cov_2d_inv"],
+                                  ref["rgb"], ref["opacities_act"], g, ref["final_T"], ref["n_contrib"], n)
+    for name in ("dL_drgb", "dL_dopacity_act", "dL_dmeans_2d", "dL_dcov_2d_inv"):
+        got = getattr(rb, name)
+        assert max_err_over_max(np_(got[base:]), want[name]) <= GRAD_TOL, name
+        assert not bool(got[:base].any()), name                  # nothing landed in a truncated address
+    del means, cov, rgb, opa, rb
+    torch.cuda.empty_cache()
+
+
 def test_project_backward_stage_parity(pkg, orc, dev):
     """Per-Gaussian chain rule on identical incoming 2-D gradients: same operation order, no
     contraction -> bit-identical to the oracle."""
