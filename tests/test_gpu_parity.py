@@ -350,6 +350,47 @@ def test_blend_with_rows_beyond_32bit_byte_offsets(pkg, orc, dev):
     torch.cuda.empty_cache()
 
 
+def test_render_with_more_than_2_26_gaussians(pkg, dev):
+    """The whole path (projection, sort, both blends, projection backward) on a model of 2^26 + 17 + 3000
+    Gaussians: all but the last 3000 sit behind the camera.  Image, contributor counts and pair list must be those
+    of the 3000 alone (bit for bit, indices shifted), the gradients theirs within the summation-order noise of the
+    atomics, and the culled rows must stay exactly zero.  Size-independent property at a size the oracle cannot
+    reach; the 3000-Gaussian view itself is oracle-checked by the tests above."""
+    w, h, n0 = 160, 120, 3000
+    base = (1 << 26) + 17
+    big = base + n0
+    arrays, cam = _scene(pkg, n0, w, h, 3, seed=8, mu_s=-3.3)
+    small = pkg.scene.to_model(arrays, dev)
+    st = pkg.RenderSettings(background=[0.1, 0.2, 0.3], active_sh_degree=3)
+    g = torch.from_numpy(pkg.scene.make_dl_dcolor(w, h)).to(dev)
+    out_s = pkg.render(small, cam, st)
+    grads_s = pkg.render_backward(g, out_s, small, cam, st)
+
+    def grow(t, fill):
+        full = torch.empty((big,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        full[:base] = torch.tensor(fill, dtype=t.dtype, device=dev).reshape((1,) + (-1,) * (t.dim() > 1) + (1,) * (t.dim() - 2))
+        full[base:] = t
+        return full
+    model = pkg.GaussianModel(positions=grow(small.positions, [0.0, 0.0, -10.0]), sh_coeffs=grow(small.sh_coeffs, [0.0]),
+                              opacities=grow(small.opacities, [0.0]), rotations=grow(small.rotations, [1.0, 0.0, 0.0, 0.0]),
+                              scales=grow(small.scales, [-4.0]))
+    out = pkg.render(model, cam, st)
+    assert out.total_pairs == out_s.total_pairs
+    assert torch.equal(out.color, out_s.color)
+    assert torch.equal(out.n_contrib, out_s.n_contrib)
+    assert torch.equal(out.tile_ranges, out_s.tile_ranges)
+    assert torch.equal(out.gaussian_indices[:out.total_pairs], out_s.gaussian_indices[:out.total_pairs] + base)
+    assert not bool(out.radii[:base].any())
+    grads = pkg.render_backward(g, out, model, cam, st)
+    for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs"):
+        got, want = getattr(grads, name), getattr(grads_s, name)
+        assert not bool(got[:base].any()), name
+        scale = float(want.abs().max())
+        assert float((got[base:] - want).abs().max()) <= 1e-5 * scale, name
+    del model, out, grads
+    torch.cuda.empty_cache()
+
+
 def test_project_backward_stage_parity(pkg, orc, dev):
     """Per-Gaussian chain rule on identical incoming 2-D gradients: same operation order, no
     contraction -> bit-identical to the oracle."""
