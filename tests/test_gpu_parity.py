@@ -729,6 +729,25 @@ def test_sort_is_memory_safe_on_inconsistent_tile_counts(pkg, orc, dev, mu_s):
     assert tr.min() >= 0 and tr.max() <= total and np.all(tr[:, 1] >= tr[:, 0])
 
 
+def test_sort_reports_a_pair_count_beyond_int32(pkg, dev):
+    """The reference indexes pairs with int (sorting.cu:146-151): more than 2^31 - 1 pairs cannot be represented.
+    40 000 splats covering 63 001 tiles each (2.52e9 pairs) must come back as an overflow error from the count - with
+    the sums carried in 64 bits on the device - not as a wrapped count and a short allocation."""
+    n, w, h = 40000, 4096, 4096
+    means = torch.full((n, 2), 2048.0, device=dev)
+    depths = torch.linspace(1.0, 9.0, n, device=dev)
+    radii = torch.full((n,), 2000, dtype=torch.int32, device=dev)
+    x0, x1 = (2048 - 2000) // 16, (2048 + 2000 + 15) // 16
+    per = (x1 - x0) ** 2
+    assert n * per > 2 ** 31
+    tiles = torch.full((n,), per, dtype=torch.int32, device=dev)
+    with pytest.raises(pkg.CugsError, match="does not fit int32"):
+        pkg.sort_gaussians(means, depths, radii, tiles, w, h)
+    # and the library is usable afterwards
+    srt = pkg.sort_gaussians(means[:10], depths[:10], radii[:10], tiles[:10], w, h)
+    assert srt.total_pairs == 10 * per
+
+
 def test_deferred_pair_count_render(pkg, orc, dev):
     """render(..., defer_count=True) returns before the host has read the sort's pair count (a training loop queues
     its loss kernels in that window); wait() / render_backward complete it.  Same image, indices and gradients as
