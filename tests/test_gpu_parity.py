@@ -737,7 +737,7 @@ def test_sort_reports_a_pair_count_beyond_int32(pkg, dev):
     means = torch.full((n, 2), 2048.0, device=dev)
     depths = torch.linspace(1.0, 9.0, n, device=dev)
     radii = torch.full((n,), 2000, dtype=torch.int32, device=dev)
-    x0, x1 = (2048 - 2000) // 16, (2048 + 2000 + 15) // 16
+    x0, x1 = (2048 - 2000) // 16, (2048 + 2000 + 1 + 15) // 16      # sorting.cu:52-57
     per = (x1 - x0) ** 2
     assert n * per > 2 ** 31
     tiles = torch.full((n,), per, dtype=torch.int32, device=dev)
@@ -746,6 +746,36 @@ def test_sort_reports_a_pair_count_beyond_int32(pkg, dev):
     # and the library is usable afterwards
     srt = pkg.sort_gaussians(means[:10], depths[:10], radii[:10], tiles[:10], w, h)
     assert srt.total_pairs == 10 * per
+
+
+@pytest.mark.parametrize("side", [4096, 4112])        # 256 tile columns: column-ordered emission; 257: three tile passes
+def test_sort_of_a_billion_pairs(pkg, dev, side):
+    """1.26e9 pairs (59 % of the int32 range): 20 000 splats, each covering the same 251 x 251 tiles, depths
+    increasing with the index.  The exact answer is known without an oracle: every covered tile lists 0 .. n-1 in
+    order, the covered tiles follow each other in tile-id order, every other tile is empty."""
+    n = 20000
+    means = torch.full((n, 2), 2048.0, device=dev)
+    depths = torch.linspace(1.0, 9.0, n, device=dev)
+    radii = torch.full((n,), 2000, dtype=torch.int32, device=dev)
+    x0, x1 = (2048 - 2000) // 16, (2048 + 2000 + 1 + 15) // 16      # sorting.cu:52-57
+    per = (x1 - x0) ** 2
+    tiles = torch.full((n,), per, dtype=torch.int32, device=dev)
+    srt = pkg.sort_gaussians(means, depths, radii, tiles, side, side)
+    total = n * per
+    assert srt.total_pairs == total and total > 1.2e9
+    vals = srt.gaussian_values_sorted
+    assert vals.shape[0] == total
+    assert torch.equal(vals.view(per, n), torch.arange(n, dtype=torch.int32, device=dev).expand(per, n))
+    ntx = (side + 15) // 16
+    covered = torch.zeros((ntx, ntx), dtype=torch.bool, device=dev)
+    covered[x0:x1, x0:x1] = True
+    rank = torch.cumsum(covered.reshape(-1).to(torch.int64), 0) - 1
+    start = torch.where(covered.reshape(-1), rank * n, torch.zeros_like(rank))
+    end = torch.where(covered.reshape(-1), (rank + 1) * n, torch.zeros_like(rank))
+    tr = srt.tile_ranges.to(torch.int64)
+    assert torch.equal(tr[:, 0], start) and torch.equal(tr[:, 1], end)
+    del srt, vals
+    torch.cuda.empty_cache()
 
 
 def test_deferred_pair_count_render(pkg, orc, dev):
