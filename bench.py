@@ -139,7 +139,7 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
         P = lambda t: C.c_void_p(t.data_ptr())
         pkg._lib.check(pkg._lib.lib.cugs_project_backward_adam(
             n, int(model.sh_coeffs.shape[2]), deg, P(model.positions), P(model.rotations), P(model.scales),
-            P(model.opacities), P(model.sh_coeffs), P(proj.radii), P(proj.rgb), C.byref(cam_abi),
+            P(model.opacities), P(model.sh_coeffs), P(proj.radii), P(proj.colour_gate), C.byref(cam_abi),
             float(settings.scale_modifier), P(rb.grad_accum), C.byref(adam), P(d_means),
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cugs_project_backward_adam")
         ev[5].record()
@@ -151,7 +151,7 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     flat = torch.empty((11 * n,), dtype=torch.float32, device=g.device) if compact else None
     pb = R.project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
                             model.opacities, model.sh_coeffs, proj.radii, cam, deg, settings.scale_modifier,
-                            grad_accum=rb.grad_accum, rgb_clamped=proj.rgb, dL_dmeans_2d_out=d_means,
+                            grad_accum=rb.grad_accum, colour_gate=proj.colour_gate, dL_dmeans_2d_out=d_means,
                             dL_drgb_gated_out=gated, skip_sh_grad=compact, geom_flat=flat)
     ev[5].record()
     grads = pkg.BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
@@ -465,7 +465,7 @@ def main():
 
     def step(events):
         if forward_only:
-            out = pkg.render(model, cam, settings)
+            out = pkg.render(model, cam, settings, for_backward=False)      # no accumulator to clear, no gate bits
             return out.total_pairs, out, None
         # under torch.distributed.run the exchange step always runs (also for a 1-rank rehearsal)
         return timed_step(pkg, model, cam, settings, g, events, exchange["mode"], launched, opt, all_centres)

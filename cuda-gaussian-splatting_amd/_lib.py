@@ -54,7 +54,7 @@ SIGNATURES = {
     "cugs_version": (C.c_char_p, []),
     "cugs_error_string": (C.c_char_p, [_I]),
     "cugs_project_forward": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, C.POINTER(Camera), _F,
-                                  _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                  _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cugs_evaluate_sh": (_I, [_I, _L, _I, _P, _P, _P, _P]),
     "cugs_evaluate_sh_backward": (_I, [_I, _L, _I, _P, _P, _P, _P, _P]),
     "cugs_pack_projected": (_I, [_L, _P, _P, _P, _P, _P, _P]),

@@ -55,6 +55,7 @@ int main(int argc, char** argv) {
         {
             cugs_hip::RenderOutput stripped = out;
             stripped.packed = torch::Tensor();
+            stripped.colour_gate = torch::Tensor();      // ... nor the gate bits: recomputed from the coefficients
             auto g2 = cugs_hip::render_backward(g, stripped, m, cam, st);
             const double scale = grads.dL_dsh_coeffs.abs().max().item<double>();
             const double diff = (g2.dL_dsh_coeffs - grads.dL_dsh_coeffs).abs().max().item<double>();

@@ -68,6 +68,7 @@ ProjectionOutput project_gaussians(const torch::Tensor& positions, const torch::
     o.opacities_act = torch::empty({n}, fopt(positions));
     o.rgb = torch::empty({n, 3}, fopt(positions));
     o.packed = torch::empty({n, CUGS_PACKED_STRIDE}, fopt(positions));
+    o.colour_gate = torch::empty({n}, torch::TensorOptions().dtype(torch::kUInt8).device(positions.device()));
     if (n == 0) return o;
     auto pos = f32c(positions), rot = f32c(rotations), scl = f32c(scales), opa = f32c(opacities), sh = f32c(sh_coeffs);
     TORCH_CHECK(sh.dim() == 3 && sh.size(0) == n && sh.size(1) == 3, "sh_coeffs must be [N, 3, C]");
@@ -75,7 +76,7 @@ ProjectionOutput project_gaussians(const torch::Tensor& positions, const torch::
                                ptr<float>(scl), ptr<float>(opa), ptr<float>(sh), &camera, scale_modifier,
                                ptr<float>(o.means_2d), ptr<float>(o.depths), ptr<float>(o.cov_2d_inv),
                                ptr<int32_t>(o.radii), ptr<int32_t>(o.tiles_touched), ptr<float>(o.opacities_act),
-                               ptr<float>(o.rgb), ptr<float>(o.packed), stream_of(positions)),
+                               ptr<float>(o.rgb), ptr<float>(o.packed), ptr<uint8_t>(o.colour_gate), stream_of(positions)),
           "cugs_project_forward");
     return o;
 }
@@ -174,7 +175,7 @@ RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const
 }
 
 namespace {
-ProjectionBackwardOutput project_backward_impl(const torch::Tensor* accum, const torch::Tensor* rgb_clamped,
+ProjectionBackwardOutput project_backward_impl(const torch::Tensor* accum, const torch::Tensor* colour_gate,
                                                torch::Tensor* d_means_out, const torch::Tensor& gm, const torch::Tensor& gc,
                                                const torch::Tensor& gr, const torch::Tensor& go,
                                                const torch::Tensor& positions, const torch::Tensor& rotations,
@@ -196,7 +197,7 @@ ProjectionBackwardOutput project_backward_impl(const torch::Tensor* accum, const
     auto cr = gr.defined() ? gr.contiguous() : gr, co = go.defined() ? go.contiguous() : go;
     check(cugs_project_backward(n, static_cast<int>(sh.size(2)), degree, ptr<float>(pos), ptr<float>(rot), ptr<float>(scl),
                                 ptr<float>(opa), ptr<float>(sh), ptr<int32_t>(rad),
-                                rgb_clamped ? ptr<float>(*rgb_clamped) : nullptr, &camera, scale_modifier,
+                                colour_gate ? ptr<uint8_t>(*colour_gate) : nullptr, &camera, scale_modifier,
                                 accum ? ptr<float>(*accum) : nullptr, ptr<float>(cm), ptr<float>(cc), ptr<float>(cr),
                                 ptr<float>(co), ptr<float>(o.dL_dpositions), ptr<float>(o.dL_drotations),
                                 ptr<float>(o.dL_dscales), ptr<float>(o.dL_dopacities), ptr<float>(o.dL_dsh_coeffs),
@@ -341,6 +342,7 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     o.means_2d = proj.means_2d; o.depths = proj.depths; o.cov_2d_inv = proj.cov_2d_inv; o.radii = proj.radii;
     o.rgb = proj.rgb; o.opacities_act = proj.opacities_act;
     o.gaussian_indices = srt.gaussian_values_sorted; o.tile_ranges = srt.tile_ranges; o.packed = proj.packed;
+    o.colour_gate = proj.colour_gate;
     o.zeroed_accum = accum;
     return o;
 }
@@ -380,17 +382,22 @@ BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutpu
         const auto& pr = fused->params();
         TORCH_CHECK(pr[0].data_ptr() == model.positions.data_ptr() && pr[1].data_ptr() == model.sh_coeffs.data_ptr(),
                     "the fused optimizer step needs the FusedAdam that was built on this model");
+        TORCH_CHECK(ro.colour_gate.defined() && ro.colour_gate.size(0) == n,
+                    "the fused optimizer step needs the colour_gate of cugs_hip::render");
         const cugs_adam_fused adam = fused->begin_fused_step();
-        auto radii = ro.radii.contiguous(), rgbc = ro.rgb.contiguous();
+        auto radii = ro.radii.contiguous(), gate = ro.colour_gate.contiguous();
         check(cugs_project_backward_adam(n, static_cast<int>(model.sh_coeffs.size(2)), degree, ptr<float>(model.positions),
                                          ptr<float>(model.rotations), ptr<float>(model.scales), ptr<float>(model.opacities),
-                                         ptr<float>(model.sh_coeffs), ptr<int32_t>(radii), ptr<float>(rgbc), &camera,
+                                         ptr<float>(model.sh_coeffs), ptr<int32_t>(radii), ptr<uint8_t>(gate), &camera,
                                          settings.scale_modifier, ptr<float>(rb.grad_accum), &adam,
                                          ptr<float>(o.dL_dmeans_2d), stream_of(dL_dcolor)),
               "cugs_project_backward_adam");
         return o;
     }
-    auto pb = project_backward_impl(&rb.grad_accum, &ro.rgb, &o.dL_dmeans_2d, {}, {}, {}, {}, model.positions,
+    // without the gate bits (a RenderOutput that went through the reference's struct) the kernel recomputes the gate
+    // from the coefficients as the reference does: the same bits, 12 C more bytes read per Gaussian
+    const bool have_gate = ro.colour_gate.defined() && ro.colour_gate.dim() == 1 && ro.colour_gate.size(0) == n;
+    auto pb = project_backward_impl(&rb.grad_accum, have_gate ? &ro.colour_gate : nullptr, &o.dL_dmeans_2d, {}, {}, {}, {}, model.positions,
                                     model.rotations, model.scales, model.opacities, model.sh_coeffs, ro.radii, camera, degree,
                                     settings.scale_modifier);
     o.dL_dpositions = pb.dL_dpositions; o.dL_drotations = pb.dL_drotations; o.dL_dscales = pb.dL_dscales;

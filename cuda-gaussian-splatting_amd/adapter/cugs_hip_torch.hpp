@@ -20,6 +20,7 @@ namespace cugs_hip {
 struct ProjectionOutput {          // rasterizer/projection.hpp
     torch::Tensor means_2d, depths, cov_2d_inv, radii, tiles_touched, rgb, opacities_act;
     torch::Tensor packed;          // [N,12] scratch for the blend kernels (not in the reference)
+    torch::Tensor colour_gate;     // [N] uint8: ReLU gate bits of the SH backward (cugs_hip.h; not in the reference)
 };
 struct SortingOutput {             // rasterizer/sorting.hpp:18-24
     torch::Tensor gaussian_keys_sorted, gaussian_values_sorted, tile_ranges;
@@ -40,6 +41,7 @@ struct RenderOutput {              // rasterizer/rasterizer.hpp:27-46
     torch::Tensor color, final_T, n_contrib, means_2d, depths, cov_2d_inv, radii, rgb, opacities_act,
         gaussian_indices, tile_ranges;
     torch::Tensor packed;
+    torch::Tensor colour_gate;     // from the projection; undefined = render_backward recomputes the gate from the coefficients
     // [N, 16] accumulator of the blend backward, already cleared by the forward blend (which leaves HBM idle); handed
     // to ONE render_backward, which takes it out of the struct (hence mutable)
     mutable torch::Tensor zeroed_accum;

@@ -56,12 +56,15 @@ struct PackedTable {
     static constexpr int kSlots = 8;
     const void* key[kSlots] = {};
     torch::Tensor packed[kSlots];
+    torch::Tensor gate[kSlots];        // [N] ReLU gate bits of the SH backward, from the projection
     torch::Tensor accum[kSlots];       // the backward's accumulator, cleared by the forward blend: newest render only, taken once
     int next = 0;
-    void put(const torch::Tensor& color, const torch::Tensor& p, const torch::Tensor& zeroed_accum = {}) {
+    void put(const torch::Tensor& color, const torch::Tensor& p, const torch::Tensor& zeroed_accum = {},
+             const torch::Tensor& colour_gate = {}) {
         for (auto& a : accum) a = torch::Tensor();                // at most one 64 B/Gaussian buffer is kept alive
         key[next] = color.defined() ? color.data_ptr() : nullptr;
         packed[next] = p;
+        gate[next] = colour_gate;
         accum[next] = zeroed_accum;
         next = (next + 1) % kSlots;
     }
@@ -73,6 +76,12 @@ struct PackedTable {
                 accum[i] = torch::Tensor();
                 return a;
             }
+        return {};
+    }
+    torch::Tensor get_gate(const torch::Tensor& color, int64_t n) const {
+        if (!color.defined()) return {};
+        for (int i = 0; i < kSlots; ++i)
+            if (key[i] == color.data_ptr() && gate[i].defined() && gate[i].size(0) == n) return gate[i];
         return {};
     }
     torch::Tensor get(const torch::Tensor& color, int64_t n) const {
@@ -88,7 +97,7 @@ inline PackedTable& packed_table() { static thread_local PackedTable t; return t
 inline RenderOutput render(const GaussianModel& model, const CameraInfo& camera, const RenderSettings& settings) {
     TORCH_CHECK(model.is_valid(), "GaussianModel is not valid");                           // rasterizer.cpp:27
     auto r = cugs_hip::render(tensors_of(model), to_pod(camera), settings_of(settings));
-    glue_detail::packed_table().put(r.color, r.packed, r.zeroed_accum);
+    glue_detail::packed_table().put(r.color, r.packed, r.zeroed_accum, r.colour_gate);
     return RenderOutput{r.color, r.final_T, r.n_contrib, r.means_2d, r.depths, r.cov_2d_inv, r.radii, r.rgb,
                         r.opacities_act, r.gaussian_indices, r.tile_ranges};
 }
@@ -97,7 +106,8 @@ inline BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const Rend
                                       const CameraInfo& camera, const RenderSettings& settings) {
     cugs_hip::RenderOutput h{ro.color, ro.final_T, ro.n_contrib, ro.means_2d, ro.depths, ro.cov_2d_inv, ro.radii, ro.rgb,
                              ro.opacities_act, ro.gaussian_indices, ro.tile_ranges,
-                             glue_detail::packed_table().get(ro.color, model.num_gaussians())};
+                             glue_detail::packed_table().get(ro.color, model.num_gaussians()),
+                             glue_detail::packed_table().get_gate(ro.color, model.num_gaussians())};
     h.zeroed_accum = glue_detail::packed_table().take_accum(ro.color, model.num_gaussians());
     auto b = cugs_hip::render_backward(dL_dcolor, h, tensors_of(model), to_pod(camera), settings_of(settings));
     return BackwardOutput{b.dL_dpositions, b.dL_drotations, b.dL_dscales, b.dL_dopacities, b.dL_dsh_coeffs, b.dL_dmeans_2d};

@@ -227,6 +227,18 @@ __device__ __forceinline__ void sh_basis(int degree, V3 d, float (&Y)[16]) {
 // colour = sum_k c_k Y_k + 0.5 in the forward kernel's association (core/sh.cu:42-76:
 // "K * c[k] * poly", i.e. (K*c)*poly, NOT c*(K*poly) as the backward's basis has it).
 // `c` points at one channel's coefficients; `stride` is the element stride between them.
+// Raw colour as the BACKWARD recomputes it for its ReLU gate (sh_backward.cu:92-99: sum of c_k * Y_k with the
+// constants folded into Y_k, then + 0.5).  Not the forward's value: there the constant multiplies the
+// coefficient first (sh.cu:44-77), so the two can differ in the last bit - and within an ulp of zero the gate the
+// reference applies is THIS one's sign, whatever the forward wrote (a forward 6e-8 with a closed gate exists).
+__device__ __forceinline__ float raw_colour_backward(const float* c, const float (&Y)[16], int num_active) {
+    float raw = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < num_active) raw += c[k] * Y[k];
+    return raw + 0.5f;
+}
+
 template <typename Ptr>
 __device__ __forceinline__ float sh_colour(int degree, Ptr c, int stride, V3 d) {
     const float x = d.x, y = d.y, z = d.z;

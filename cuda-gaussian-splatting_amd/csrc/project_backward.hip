@@ -8,9 +8,11 @@
 //
 // gfx950 mapping: one thread per Gaussian.  The [n,3,C] gradient rows (the largest write of the
 // whole backward, 12C B/Gaussian) are assembled per thread in LDS (odd dword row stride) and
-// leave the workgroup as contiguous 16-byte stores.  With the forward's clamped rgb available
-// the ReLU gate needs no re-read of the coefficients (raw > 0 <=> clamped > 0, sh_backward.cu:92-100),
-// which removes 12C B/Gaussian of reads.  Bound: HBM; algorithmic bytes 44+4+64(+12) read,
+// leave the workgroup as contiguous 16-byte stores.  The ReLU gate (sh_backward.cu:92-100 recomputes the
+// raw colour from the coefficients) comes as three bits per Gaussian from cugs_project_forward, which has the
+// coefficients in LDS anyway and makes the backward's own test there (colour_gate): no re-read of the
+// 12C B/Gaussian coefficients.  (The forward's clamped rgb is NOT a substitute: its rounding differs from the
+// backward's recomputation, and within an ulp of zero the two disagree.)  Bound: HBM; algorithmic bytes 44+4+64(+1) read,
 // 44+12C(+8) written per Gaussian.
 #include "cugs_gaussian_math.h"
 
@@ -162,14 +164,6 @@ __device__ __forceinline__ void adam_sh_rows(float* __restrict__ param, float* _
 
 __device__ __forceinline__ int active_count(int degree) { return (degree + 1) * (degree + 1); }
 
-// raw colour as the backward recomputes it (sh_backward.cu:92-96: sum of c_k * Y_k, then + 0.5)
-__device__ __forceinline__ float raw_colour(const float* c, const float (&Y)[16], int num_active) {
-    float raw = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-        if (k < num_active) raw += c[k] * Y[k];
-    return raw + 0.5f;
-}
 
 // dL/dSigma' from dL/dSigma'^-1 (backward.cuh:37-64): -S^-1 G S^-1 with the incoming
 // off-diagonal halved (Q3).
@@ -246,7 +240,7 @@ __device__ __forceinline__ void add_grad_t_from_cov(const Sym2& g, const Sym3& S
 
 struct PBPtrs {
     const float* positions; const float* rotations; const float* scales; const float* opacities;
-    const float* sh; const int32_t* radii; const float* rgb_clamped;
+    const float* sh; const int32_t* radii; const uint8_t* colour_gate;
     const float* grad_accum;
     const float* g_means; const float* g_cov; const float* g_rgb; const float* g_opa;
     float* d_pos; float* d_rot; float* d_scl; float* d_opa; float* d_sh; float* d_means_out;
@@ -271,7 +265,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     // parameters are streamed (non-temporal) unless the fused optimizer step reads them again further down
     auto ldp = [](const float* q_) { return ADAM ? *q_ : cugs_ldnt(q_); };
 
-    const bool gate_from_sh = (p.rgb_clamped == nullptr);      // kernel-uniform
+    const bool gate_from_sh = (p.colour_gate == nullptr);      // kernel-uniform
     if (gate_from_sh) {
         load_sh_rows<C, ALIGNED>(p.sh, base, count, s_sh);
         __syncthreads();
@@ -302,8 +296,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             bool open;
-            if (gate_from_sh) open = raw_colour(s_sh + threadIdx.x * LROW + ch * C, Y, num_active) > 0.0f;
-            else open = p.rgb_clamped[idx * 3 + ch] > 0.0f;
+            if (gate_from_sh) open = raw_colour_backward(s_sh + threadIdx.x * LROW + ch * C, Y, num_active) > 0.0f;
+            else open = ((p.colour_gate[idx] >> ch) & 1u) != 0u;      // the same test, made by cugs_project_forward
             gated[ch] = g_rgb[ch] * (open ? 1.0f : 0.0f);          // sh_backward.cu:99-100
             if (p.d_rgb_gated_out) p.d_rgb_gated_out[idx * 3 + ch] = gated[ch];
         }
@@ -433,7 +427,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_sh_backward(int64_t n, int degre
         sh_basis(degree, V3{dirs[idx * 3 + 0], dirs[idx * 3 + 1], dirs[idx * 3 + 2]}, Y);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const bool open = raw_colour(s_sh + threadIdx.x * LROW + ch * C, Y, num_active) > 0.0f;
+            const bool open = raw_colour_backward(s_sh + threadIdx.x * LROW + ch * C, Y, num_active) > 0.0f;
             gated[ch] = dL_dcolor[idx * 3 + ch] * (open ? 1.0f : 0.0f);
         }
     }
@@ -571,7 +565,7 @@ int launch_shb(int64_t n, int degree, const float* sh, const float* dirs, const 
 
 extern "C" int cugs_project_backward(int64_t n, int num_coeffs, int active_degree, const float* positions,
                                      const float* rotations, const float* scales, const float* opacities,
-                                     const float* sh_coeffs, const int32_t* radii, const float* rgb_clamped,
+                                     const float* sh_coeffs, const int32_t* radii, const uint8_t* colour_gate,
                                      const cugs_camera* camera_host, float scale_modifier,
                                      const float* grad_accum, const float* dL_dmeans_2d,
                                      const float* dL_dcov_2d_inv, const float* dL_drgb,
@@ -587,16 +581,16 @@ extern "C" int cugs_project_backward(int64_t n, int num_coeffs, int active_degre
         !dL_dscales || !dL_dopacities)
         return CUGS_EINVAL;
     if (!dL_dsh_coeffs && !dL_drgb_gated_out) return CUGS_EINVAL;   // one of the two colour-gradient outputs
-    if (!rgb_clamped && !sh_coeffs) return CUGS_EINVAL;
+    if (!colour_gate && !sh_coeffs) return CUGS_EINVAL;
     if (!grad_accum && (!dL_dmeans_2d || !dL_dcov_2d_inv || !dL_drgb || !dL_dopacity_act)) return CUGS_EINVAL;
     if (grad_accum && !cugs_aligned16(grad_accum)) return CUGS_EALIGN;
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
-    PBPtrs p{positions, rotations, scales, opacities, sh_coeffs, radii, rgb_clamped, grad_accum,
+    PBPtrs p{positions, rotations, scales, opacities, sh_coeffs, radii, colour_gate, grad_accum,
              dL_dmeans_2d, dL_dcov_2d_inv, dL_drgb, dL_dopacity_act, dL_dpositions, dL_drotations,
              dL_dscales, dL_dopacities, dL_dsh_coeffs, dL_dmeans_2d_out, dL_drgb_gated_out,
              nullptr, nullptr, nullptr, nullptr, nullptr};
     const bool aligned = (!dL_dsh_coeffs || cugs_aligned16(dL_dsh_coeffs)) && cugs_aligned16(rotations) && cugs_aligned16(dL_drotations) &&
-                         (rgb_clamped || cugs_aligned16(sh_coeffs));
+                         (colour_gate || cugs_aligned16(sh_coeffs));
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (num_coeffs) {
         case 1: return launch_pb<1>(n, active_degree, cam, p, aligned, st);
@@ -608,7 +602,7 @@ extern "C" int cugs_project_backward(int64_t n, int num_coeffs, int active_degre
 
 extern "C" int cugs_project_backward_adam(int64_t n, int num_coeffs, int active_degree, float* positions,
                                           float* rotations, float* scales, float* opacities, float* sh_coeffs,
-                                          const int32_t* radii, const float* rgb_clamped,
+                                          const int32_t* radii, const uint8_t* colour_gate,
                                           const cugs_camera* camera_host, float scale_modifier,
                                           const float* grad_accum, const cugs_adam_fused* adam_host,
                                           float* dL_dmeans_2d_out, void* stream) {
@@ -617,7 +611,7 @@ extern "C" int cugs_project_backward_adam(int64_t n, int num_coeffs, int active_
     if ((active_degree + 1) * (active_degree + 1) > num_coeffs) return CUGS_EINVAL;
     if (num_coeffs != 1 && num_coeffs != 4 && num_coeffs != 9 && num_coeffs != 16) return CUGS_EINVAL;
     if (n == 0) return 0;
-    if (!positions || !rotations || !scales || !opacities || !sh_coeffs || !radii || !rgb_clamped || !grad_accum)
+    if (!positions || !rotations || !scales || !opacities || !sh_coeffs || !radii || !colour_gate || !grad_accum)
         return CUGS_EINVAL;
     if (!cugs_aligned16(grad_accum)) return CUGS_EALIGN;
     AdamFusedArgs a;
@@ -628,7 +622,7 @@ extern "C" int cugs_project_backward_adam(int64_t n, int num_coeffs, int active_
     a.beta1 = adam_host->beta1; a.beta2 = adam_host->beta2; a.eps = adam_host->eps;
     a.bc1 = adam_host->bc1; a.bc2 = adam_host->bc2;
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
-    PBPtrs p{positions, rotations, scales, opacities, sh_coeffs, radii, rgb_clamped, grad_accum,
+    PBPtrs p{positions, rotations, scales, opacities, sh_coeffs, radii, colour_gate, grad_accum,
              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dL_dmeans_2d_out, nullptr,
              positions, rotations, scales, opacities, sh_coeffs};
     const bool aligned = cugs_aligned16(rotations) && cugs_aligned16(sh_coeffs) && cugs_aligned16(a.m[1]) &&

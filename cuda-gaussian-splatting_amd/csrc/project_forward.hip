@@ -83,7 +83,7 @@ struct ProjPtrs {
     const float* positions; const float* rotations; const float* scales; const float* opacities;
     const float* sh;
     float* means_2d; float* depths; float* cov_2d_inv; int32_t* radii; int32_t* tiles_touched;
-    float* opacities_act; float* rgb; float* packed;
+    float* opacities_act; float* rgb; float* packed; uint8_t* colour_gate;
 };
 
 template <int C, bool ALIGNED>
@@ -119,6 +119,18 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
     for (int ch = 0; ch < 3; ++ch) {
         float raw = sh_colour(degree, row + ch * C, 1, dir);
         col[ch] = (raw < 0.0f) ? 0.0f : raw;
+    }
+    // the ReLU gate of the SH backward, made here while the coefficients are in LDS: bit ch = the backward's own
+    // recomputation of channel ch is > 0 (sh_backward.cu:92-99) - not `col[ch] > 0`, see raw_colour_backward
+    if (p.colour_gate) {                                               // kernel-uniform
+        float Y[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        sh_basis(degree, dir, Y);
+        const int num_active = (degree + 1) * (degree + 1);
+        unsigned bits = 0u;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            bits |= (raw_colour_backward(row + ch * C, Y, num_active) > 0.0f) ? (1u << ch) : 0u;
+        p.colour_gate[idx] = (uint8_t)bits;
     }
 
     // --- geometry ---
@@ -275,7 +287,8 @@ extern "C" int cugs_project_forward(int64_t n, int num_coeffs, int active_degree
                                     const float* sh_coeffs, const cugs_camera* camera_host,
                                     float scale_modifier, float* means_2d, float* depths,
                                     float* cov_2d_inv, int32_t* radii, int32_t* tiles_touched,
-                                    float* opacities_act, float* rgb, float* packed, void* stream) {
+                                    float* opacities_act, float* rgb, float* packed, uint8_t* colour_gate,
+                                    void* stream) {
     if (n < 0 || !camera_host) return CUGS_EINVAL;
     if (active_degree < 0 || active_degree > 3) return CUGS_EINVAL;
     if ((active_degree + 1) * (active_degree + 1) > num_coeffs) return CUGS_EINVAL;
@@ -289,7 +302,7 @@ extern "C" int cugs_project_forward(int64_t n, int num_coeffs, int active_degree
 
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
     ProjPtrs p{positions, rotations, scales, opacities, sh_coeffs, means_2d, depths, cov_2d_inv,
-               radii, tiles_touched, opacities_act, rgb, packed};
+               radii, tiles_touched, opacities_act, rgb, packed, colour_gate};
     const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rotations) && cugs_aligned16(rgb) &&
                          cugs_aligned16(cov_2d_inv) && (reinterpret_cast<uintptr_t>(means_2d) & 7u) == 0;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -134,6 +134,7 @@ class ProjectionOutput:
     rgb: torch.Tensor
     opacities_act: torch.Tensor
     packed: Optional[torch.Tensor] = None      # [N,12] scratch for the blend kernels (not in the reference)
+    colour_gate: Optional[torch.Tensor] = None # [N] uint8: the SH backward's ReLU gate bits (not in the reference)
 
 
 @dataclass
@@ -185,6 +186,7 @@ class RenderOutput:
     gaussian_indices: torch.Tensor
     tile_ranges: torch.Tensor
     packed: Optional[torch.Tensor] = None       # scratch kept alive for render_backward
+    colour_gate: Optional[torch.Tensor] = None  # [N] uint8 ReLU gate bits of the SH backward, from the projection
     total_pairs: int = 0
     zeroed_accum: Optional[torch.Tensor] = None # [N,16] accumulator already cleared by the forward blend (one backward)
     pending: Optional[object] = None            # render(..., defer_count=True): the sort's pair count has not been read yet

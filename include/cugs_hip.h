@@ -58,14 +58,18 @@ const char* cugs_error_string(int code);
  * sh_coeffs [n,3,num_coeffs]; active_degree in 0..3 with (active_degree+1)^2 <= num_coeffs.
  * Outputs: means_2d [n,2], depths [n], cov_2d_inv [n,3], radii [n] i32, tiles_touched [n] i32,
  * opacities_act [n], rgb [n,3] (clamped).  `packed` ([n,CUGS_PACKED_STRIDE] floats, 16-byte
- * aligned) is optional scratch consumed by cugs_rasterize_*; pass NULL to skip it. */
+ * aligned) is optional scratch consumed by cugs_rasterize_*; pass NULL to skip it.
+ * `colour_gate` ([n] bytes, optional): bit ch = the SH backward's ReLU gate of channel ch, i.e. the sign test of
+ * the colour AS THE BACKWARD RECOMPUTES IT (sh_backward.cu:92-99), made here while the coefficients are on
+ * chip; cugs_project_backward takes it instead of re-reading them.  rgb > 0 is not that test: forward (sh.cu:44-77)
+ * and backward round differently, and within an ulp of zero they disagree. */
 int cugs_project_forward(int64_t n, int num_coeffs, int active_degree,
                          const float* positions, const float* rotations, const float* scales,
                          const float* opacities, const float* sh_coeffs,
                          const cugs_camera* camera_host, float scale_modifier,
                          float* means_2d, float* depths, float* cov_2d_inv, int32_t* radii,
                          int32_t* tiles_touched, float* opacities_act, float* rgb,
-                         float* packed, void* stream);
+                         float* packed, uint8_t* colour_gate, void* stream);
 
 /* ---- a4: evaluate_sh_cuda (core/sh.cu:81-123), output NOT clamped ------------------- */
 int cugs_evaluate_sh(int degree, int64_t n, int num_coeffs, const float* sh_coeffs,
@@ -173,16 +177,17 @@ int cugs_rasterize_backward_prezeroed(int width, int height, const float backgro
 /* ---- a8+a9: project_backward (projection_backward.cu:253-344, kernel :26-247) -------
  * One launch: k_project_backward + directions + k_evaluate_sh_backward.  The incoming 2-D
  * gradients come either from grad_accum (packed rows, preferred) or, when grad_accum is
- * NULL, from the four reference-layout arrays.  rgb_clamped (the forward's rgb) supplies
- * the ReLU gate (raw > 0 <=> clamped > 0, sh_backward.cu:92-100); when NULL the gate is
- * recomputed from sh_coeffs as the reference does.  dL_dmeans_2d_out ([n,2], may be NULL)
+ * NULL, from the four reference-layout arrays.  colour_gate ([n] bytes from cugs_project_forward of
+ * the same model, camera and degree) supplies the ReLU gate (sh_backward.cu:92-100); when NULL the gate is
+ * recomputed from sh_coeffs as the reference does - the same bits, 12 num_coeffs more bytes read per
+ * Gaussian.  dL_dmeans_2d_out ([n,2], may be NULL)
  * receives BackwardOutput::dL_dmeans_2d (rasterizer.cpp:184) when grad_accum is used.
  * dL_dsh_coeffs may be NULL when dL_drgb_gated_out ([n,3]: dL_drgb with the ReLU gate applied) is
  * given instead: the data-parallel exchange (cugs_sh_backward_views) rebuilds the SH gradient from it. */
 int cugs_project_backward(int64_t n, int num_coeffs, int active_degree,
                           const float* positions, const float* rotations, const float* scales,
                           const float* opacities, const float* sh_coeffs, const int32_t* radii,
-                          const float* rgb_clamped, const cugs_camera* camera_host,
+                          const uint8_t* colour_gate, const cugs_camera* camera_host,
                           float scale_modifier, const float* grad_accum,
                           const float* dL_dmeans_2d, const float* dL_dcov_2d_inv,
                           const float* dL_drgb, const float* dL_dopacity_act,
@@ -195,7 +200,7 @@ int cugs_project_backward(int64_t n, int num_coeffs, int active_degree,
  * (fused_adam.cu:44-76) to each Gaussian's own parameters as soon as its gradients exist, so the five gradient
  * tensors (236 B/Gaussian at degree 3) are neither written nor read back by an optimizer launch.  Same
  * arithmetic in the same order as cugs_project_backward followed by cugs_fused_adam_groups: identical bits.
- * The parameters are updated IN PLACE; the 2-D gradients come from grad_accum, the ReLU gate from rgb_clamped
+ * The parameters are updated IN PLACE; the 2-D gradients come from grad_accum, the ReLU gate from colour_gate
  * (both required).  adam_host: moments and learning rates in ParamGroup order {positions, sh_coeffs,
  * opacities, scales, rotations} (lr_schedule.hpp:23-29), bc1/bc2 from cugs_adam_bias_correction.  Not for
  * data-parallel training: there the gradients must be exchanged between backward and optimizer. */
@@ -207,7 +212,7 @@ typedef struct cugs_adam_fused {
 } cugs_adam_fused;
 int cugs_project_backward_adam(int64_t n, int num_coeffs, int active_degree, float* positions,
                                float* rotations, float* scales, float* opacities, float* sh_coeffs,
-                               const int32_t* radii, const float* rgb_clamped,
+                               const int32_t* radii, const uint8_t* colour_gate,
                                const cugs_camera* camera_host, float scale_modifier,
                                const float* grad_accum, const cugs_adam_fused* adam_host,
                                float* dL_dmeans_2d_out, void* stream);

@@ -509,13 +509,17 @@ void orc_rasterize_forward(int img_w, int img_h, const float bg[3], const int32_
  * Quirks kept: contributors counted from the END of the list (backward.cu:140-145),
  * T /= max(1-alpha, 1e-5) (:150-151), clamp gate on o*exp(power) >= 0.99 (:181-191),
  * combined off-diagonal dL/db = -dx*dy (:211). */
-void orc_rasterize_backward_rows(int img_w, int img_h, int row0, int row1, const float bg[3],
+/* mag (optional, [n,9] doubles, zeroed by the caller): the MAGNITUDES the sums are made of - what bounds the error of
+ * any fp32 summation of them (tools/fuzz_parity.py uses it to tell summation noise on a cancelling sum from a wrong
+ * gradient): sum |drgb_c| (3), sum |dL_dopa|, sum |dpw dx|, sum |dpw dy|, sum |dpw| dx^2, sum |dpw dx dy|,
+ * sum |dpw| dy^2 (dpw = dL_dpower). */
+static void rasterize_backward_rows_impl(int img_w, int img_h, int row0, int row1, const float bg[3],
                                  const int32_t* tile_ranges, const int32_t* gaussian_idx,
                                  const float* means_2d, const float* cov_2d_inv, const float* rgb,
                                  const float* opacities, const float* dL_dcolor,
                                  const float* final_T, const int32_t* n_contrib, int n_gaussians,
                                  float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
-                                 float* dL_dcov_2d_inv) {
+                                 float* dL_dcov_2d_inv, double* mag) {
     int ntx = (img_w + TILE - 1) / TILE;
     (void)img_h;
     double* acc = (double*)calloc((size_t)(n_gaussians > 0 ? n_gaussians : 1) * 9, sizeof(double));
@@ -563,6 +567,13 @@ void orc_rasterize_backward_rows(int img_w, int img_h, int row0, int row1, const
                 double* A = acc + (size_t)g * 9;
                 A[0] += dr0; A[1] += dr1; A[2] += dr2; A[3] += dL_dopa;
                 A[4] += dmx; A[5] += dmy; A[6] += da; A[7] += db; A[8] += dc;
+                if (mag) {
+                    double* M = mag + (size_t)g * 9;
+                    double pw = fabs((double)dL_dpower), ax = fabs((double)dx), ay = fabs((double)dy);
+                    M[0] += fabs((double)dr0); M[1] += fabs((double)dr1); M[2] += fabs((double)dr2);
+                    M[3] += fabs((double)dL_dopa);
+                    M[4] += pw * ax; M[5] += pw * ay; M[6] += pw * ax * ax; M[7] += pw * ax * ay; M[8] += pw * ay * ay;
+                }
             }
         }
     for (int g = 0; g < n_gaussians; ++g) {
@@ -575,6 +586,30 @@ void orc_rasterize_backward_rows(int img_w, int img_h, int row0, int row1, const
         dL_dcov_2d_inv[g * 3 + 2] = (float)A[8];
     }
     free(acc);
+}
+
+void orc_rasterize_backward_rows(int img_w, int img_h, int row0, int row1, const float bg[3],
+                                 const int32_t* tile_ranges, const int32_t* gaussian_idx,
+                                 const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                 const float* opacities, const float* dL_dcolor,
+                                 const float* final_T, const int32_t* n_contrib, int n_gaussians,
+                                 float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
+                                 float* dL_dcov_2d_inv) {
+    rasterize_backward_rows_impl(img_w, img_h, row0, row1, bg, tile_ranges, gaussian_idx, means_2d, cov_2d_inv, rgb,
+                                 opacities, dL_dcolor, final_T, n_contrib, n_gaussians, dL_drgb, dL_dopacity_act,
+                                 dL_dmeans_2d, dL_dcov_2d_inv, NULL);
+}
+
+/* the same sums plus their magnitudes (see rasterize_backward_rows_impl) */
+void orc_rasterize_backward_magnitudes(int img_w, int img_h, const float bg[3], const int32_t* tile_ranges,
+                                       const int32_t* gaussian_idx, const float* means_2d, const float* cov_2d_inv,
+                                       const float* rgb, const float* opacities, const float* dL_dcolor,
+                                       const float* final_T, const int32_t* n_contrib, int n_gaussians,
+                                       float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
+                                       float* dL_dcov_2d_inv, double* mag) {
+    rasterize_backward_rows_impl(img_w, img_h, 0, img_h, bg, tile_ranges, gaussian_idx, means_2d, cov_2d_inv, rgb,
+                                 opacities, dL_dcolor, final_T, n_contrib, n_gaussians, dL_drgb, dL_dopacity_act,
+                                 dL_dmeans_2d, dL_dcov_2d_inv, mag);
 }
 
 void orc_rasterize_backward(int img_w, int img_h, const float bg[3], const int32_t* tile_ranges,

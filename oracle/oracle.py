@@ -138,6 +138,25 @@ def rasterize_backward(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_inv, rgb, o
     return out
 
 
+def rasterize_backward_magnitudes(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_inv, rgb, opacities, dL_dcolor,
+                                  final_T, n_contrib, n):
+    """rasterize_backward plus `mag` [n, 9] (float64): the sums of the MAGNITUDES of the terms of each accumulated
+    gradient - sum |drgb_c| (3), sum |dL_dopa|, sum |dpw dx|, sum |dpw dy|, sum |dpw| dx^2, sum |dpw dx dy|,
+    sum |dpw| dy^2 - which bound the rounding error of any fp32 summation of those terms."""
+    bg_a = _f(bg)
+    tr, gi = _i(tile_ranges), _i(gidx)
+    m, c, r, o = _f(means_2d), _f(cov_2d_inv), _f(rgb), _f(opacities)
+    g, ft, nc = _f(dL_dcolor), _f(final_T), _i(n_contrib)
+    out = dict(dL_drgb=np.empty((n, 3), np.float32), dL_dopacity_act=np.empty(n, np.float32),
+               dL_dmeans_2d=np.empty((n, 2), np.float32), dL_dcov_2d_inv=np.empty((n, 3), np.float32),
+               mag=np.zeros((n, 9), np.float64))
+    _lib.orc_rasterize_backward_magnitudes(C.c_int(w), C.c_int(h), _p(bg_a), _p(tr), _p(gi), _p(m), _p(c), _p(r), _p(o),
+                                           _p(g), _p(ft), _p(nc), C.c_int(n), _p(out["dL_drgb"]),
+                                           _p(out["dL_dopacity_act"]), _p(out["dL_dmeans_2d"]),
+                                           _p(out["dL_dcov_2d_inv"]), _p(out["mag"]))
+    return out
+
+
 def project_backward(positions, rotations, scales, opacities, view, fx, fy, cx, cy, scale_mod, radii,
                      dL_dmeans_2d, dL_dcov_2d_inv, dL_dopacity_act):
     n = positions.shape[0]

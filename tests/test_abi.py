@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu(pkg):
     null = C.c_void_p(0)
     # degree out of range / too few coefficients / unsupported coefficient count -> CUGS_EINVAL
     args = lambda n, c, d: (n, c, d, null, null, null, null, null, C.byref(cam), 1.0, null, null, null, null, null,
-                            null, null, null, null)
+                            null, null, null, null, null)
     assert lib.cugs_project_forward(*args(10, 16, 4)) == -1
     assert lib.cugs_project_forward(*args(10, 4, 2)) == -1
     assert lib.cugs_project_forward(*args(10, 5, 1)) == -1

