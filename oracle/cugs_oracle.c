@@ -512,7 +512,7 @@ void orc_rasterize_forward(int img_w, int img_h, const float bg[3], const int32_
 /* mag (optional, [n,9] doubles, zeroed by the caller): the MAGNITUDES the sums are made of - what bounds the error of
  * any fp32 summation of them (tools/fuzz_parity.py uses it to tell summation noise on a cancelling sum from a wrong
  * gradient): sum |drgb_c| (3), sum |dL_dopa|, sum |dpw dx|, sum |dpw dy|, sum |dpw| dx^2, sum |dpw dx dy|,
- * sum |dpw| dy^2 (dpw = dL_dpower). */
+ * sum |dpw| dy^2 (dpw = dL_dpower), where dL_dopa and dpw enter with the magnitude of the OPERANDS of dL_dalpha. */
 static void rasterize_backward_rows_impl(int img_w, int img_h, int row0, int row1, const float bg[3],
                                  const int32_t* tile_ranges, const int32_t* gaussian_idx,
                                  const float* means_2d, const float* cov_2d_inv, const float* rgb,
@@ -555,6 +555,7 @@ static void rasterize_backward_rows_impl(int img_w, int img_h, int row0, int row
                 dL_dalpha += dC0 * (T * r0 - S0 / one_minus_alpha);
                 dL_dalpha += dC1 * (T * r1 - S1 / one_minus_alpha);
                 dL_dalpha += dC2 * (T * r2 - S2 / one_minus_alpha);
+                const float S0m = S0, S1m = S1, S2m = S2;               /* the S this contribution was differenced against */
                 S0 += weight * r0; S1 += weight * r1; S2 += weight * r2;
                 float dL_dopa = dL_dalpha * exp_power;
                 float dL_dpower = dL_dalpha * alpha;
@@ -568,10 +569,17 @@ static void rasterize_backward_rows_impl(int img_w, int img_h, int row0, int row
                 A[0] += dr0; A[1] += dr1; A[2] += dr2; A[3] += dL_dopa;
                 A[4] += dmx; A[5] += dmy; A[6] += da; A[7] += db; A[8] += dc;
                 if (mag) {
+                    /* dL/dalpha is itself a difference - per channel T r_c against S_c / (1 - alpha), then over the
+                     * channels (and, in the product, T G against D / (1 - alpha)): its magnitude is that of the
+                     * operands, not of the result */
                     double* M = mag + (size_t)g * 9;
-                    double pw = fabs((double)dL_dpower), ax = fabs((double)dx), ay = fabs((double)dy);
+                    double da_mag = fabs((double)dC0) * (fabs((double)T * r0) + fabs((double)S0m) / one_minus_alpha)
+                                  + fabs((double)dC1) * (fabs((double)T * r1) + fabs((double)S1m) / one_minus_alpha)
+                                  + fabs((double)dC2) * (fabs((double)T * r2) + fabs((double)S2m) / one_minus_alpha);
+                    int clamped = (o * exp_power >= 0.99f);
+                    double pw = clamped ? 0.0 : da_mag * alpha, ax = fabs((double)dx), ay = fabs((double)dy);
                     M[0] += fabs((double)dr0); M[1] += fabs((double)dr1); M[2] += fabs((double)dr2);
-                    M[3] += fabs((double)dL_dopa);
+                    M[3] += clamped ? 0.0 : da_mag * exp_power;
                     M[4] += pw * ax; M[5] += pw * ay; M[6] += pw * ax * ax; M[7] += pw * ax * ay; M[8] += pw * ay * ay;
                 }
             }

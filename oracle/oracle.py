@@ -142,7 +142,9 @@ def rasterize_backward_magnitudes(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_
                                   final_T, n_contrib, n):
     """rasterize_backward plus `mag` [n, 9] (float64): the sums of the MAGNITUDES of the terms of each accumulated
     gradient - sum |drgb_c| (3), sum |dL_dopa|, sum |dpw dx|, sum |dpw dy|, sum |dpw| dx^2, sum |dpw dx dy|,
-    sum |dpw| dy^2 - which bound the rounding error of any fp32 summation of those terms."""
+    sum |dpw| dy^2 - which bound the rounding error of any fp32 evaluation and summation of those terms.  dL_dopa
+    and dpw = dL_dpower enter with the magnitude of the OPERANDS of dL_dalpha (a difference per channel and over the
+    channels), not of its value."""
     bg_a = _f(bg)
     tr, gi = _i(tile_ranges), _i(gidx)
     m, c, r, o = _f(means_2d), _f(cov_2d_inv), _f(rgb), _f(opacities)

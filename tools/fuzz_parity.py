@@ -20,7 +20,7 @@ def summation_noise_only(pkg, orc, out, ref, g, bg, n, w, h, dev):
     oracle's operation order on identical inputs (bit-identical stage test), so everything the GPU can differ by sits
     in the nine 2-D accumulators of the blend backward.  Each is a sum of terms the oracle can list: the error of ANY
     fp32 evaluation and summation of them is bounded by B * sum |terms| (B = 32 * 2^-24 covers the per-term rounding
-    of the GPU's v_rcp/FMA forms and a 16-deep summation tree).  The GPU sums the geometry in moment form, so its
+    of the GPU's v_rcp/FMA forms and the in-wave summation tree; the atomic adds come on top, see below).  The GPU sums the geometry in moment form, so its
     terms are |dpw dx|, |dpw dy|, ... combined with |a|, |b|, |c| - the bound uses those."""
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rb = pkg.rasterize_backward(t(g), out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges,
@@ -28,12 +28,16 @@ def summation_noise_only(pkg, orc, out, ref, g, bg, n, w, h, dev):
     want = orc.rasterize_backward_magnitudes(w, h, bg, ref["tile_ranges"], ref["values"], ref["means_2d"],
                                              ref["cov_2d_inv"], ref["rgb"], ref["opacities_act"], g, ref["final_T"],
                                              ref["n_contrib"], n)
-    B = 32.0 * 2.0 ** -24
+    # ... plus one rounding per atomic add into the Gaussian's row: at most four (one per quad wave) for each of its
+    # list entries.  Only the Q12 dump pile - Gaussian 0 standing in for every splat that is off screen in both axes,
+    # thousands of times in tile 0 - makes that term matter; the reference's per-pixel atomics are 64 times as many.
+    entries = np.bincount(ref["values"], minlength=n).astype(np.float64)
+    B = ((32.0 + 4.0 * entries) * 2.0 ** -24)[:, None]
     mag = want["mag"]
     a, b, c = (np.abs(ref["cov_2d_inv"][:, i].astype(np.float64)) for i in range(3))
     bound = {
         "dL_drgb": mag[:, 0:3],
-        "dL_dopacity_act": mag[:, 3],
+        "dL_dopacity_act": mag[:, 3:4],
         "dL_dmeans_2d": np.stack([a * mag[:, 4] + b * mag[:, 5], b * mag[:, 4] + c * mag[:, 5]], axis=1),
         "dL_dcov_2d_inv": np.stack([0.5 * mag[:, 6], mag[:, 7], 0.5 * mag[:, 8]], axis=1),
     }
