@@ -1,7 +1,8 @@
 """Randomised parity sweep (not part of the test suite): many small random scenes - sizes, image shapes, SH degrees,
 splat scales from sub-pixel to screen-filling, views, backgrounds, scale modifiers - rendered and differentiated on
 the GPU and by the oracle.  Integers, order, tile ranges, n_contrib and the image must be bit-equal, gradients within
-1e-4 of each tensor's scale.    python tools/fuzz_parity.py [cases] [seed]"""
+1e-4 of each tensor's scale.    python tools/fuzz_parity.py [cases] [seed] [dense|extra]
+FUZZ_ONLY=<k> replays case k of a sweep with a per-tensor report."""
 import os
 import sys
 
@@ -58,6 +59,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     dense = len(sys.argv) > 3 and sys.argv[3] == "dense"      # larger, denser scenes: the sort's column route, long lists
+    extra_mode = len(sys.argv) > 3 and sys.argv[3] == "extra"
     only = int(os.environ.get("FUZZ_ONLY", "-1"))             # replay ONE case of a sweep (same draws), with a report
     pkg, orc = ge.load_package(), ge.load_oracle()
     dev = torch.device("cuda:0")
@@ -82,7 +84,13 @@ def main():
         g_scale = np.float32(rng.choice([1.0, 1000.0]))
         if only >= 0 and k != only:
             continue                                                            # same draws, no work: replays one case
-        arrays = pkg.scene.make_gaussians(n, max(w, 8), max(h, 8), sh_degree=deg, seed=scene_seed, mu_s=mu_s)
+        # mode "extra": variations added after the first sweeps were logged, drawn from a per-case generator and only on
+        # request, so that (seed, k) still names the case it named in profiles/*_fuzz_parity.log
+        stored_deg = deg
+        if extra_mode:
+            extra = np.random.default_rng([seed, k, 1])
+            stored_deg = int(extra.integers(deg, 4))                                     # more coefficients stored than active
+        arrays = pkg.scene.make_gaussians(n, max(w, 8), max(h, 8), sh_degree=stored_deg, seed=scene_seed, mu_s=mu_s)
         if opa_shift is not None:
             arrays["opacities"] += opa_shift                                    # faint / opaque (clamp gate, saturation)
         if spread:
@@ -119,11 +127,12 @@ def main():
                     print("   got row ", got.reshape(got.shape[0], -1)[i], "\n   want row", refb[name].reshape(got.shape[0], -1)[i],
                           "\n   rgb", ref["rgb"][i], "position", arrays["positions"][i], flush=True)
             if err > 1e-4 and summation_noise_only(pkg, orc, out, ref, g, bg, n, w, h, dev):
-                # a sum whose terms cancel to ~1e-4 of their magnitudes (typical: ONE splat, random-sign dL/dcolor):
-                # no fp32 summation order - the reference's atomics included - meets 1e-4 of the RESULT there
+                # a sum whose terms cancel to ~1e-4 of their magnitudes (typical: ONE splat, random-sign dL/dcolor), or 2-D
+                # gradients that agree to 1e-6 going through an ill-conditioned chain rule (a screen-filling splat): no
+                # fp32 evaluation - the reference's own included - meets 1e-4 of the RESULT there
                 ill += 1
-                print(tag, "%s: %.2e of the tensor's scale, every 2-D accumulator within the fp32 summation bound of "
-                      "its terms: cancellation, not counted" % (name, err), flush=True)
+                print(tag, "%s: %.2e of the tensor's scale, every 2-D accumulator within the fp32 bound of its terms: "
+                      "cancellation (in the sums, or in the chain rule behind them), not counted" % (name, err), flush=True)
                 continue
             worst = max(worst, err)
             assert err <= 1e-4, (tag, name, err)
