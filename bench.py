@@ -476,25 +476,6 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    if args.exchange == "auto" and launched and (world > 1 or args.rehearse_calibration) and not forward_only:
-        # which exchange is faster depends on what RCCL makes of this node's xGMI links: measure, don't guess.
-        # Untimed, before the warmup; every rank takes the same decision (MAX over ranks of each time).
-        cal = []
-        for mode in ("compact", "allreduce"):
-            exchange["mode"] = mode
-            step(None)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                step(None)
-            fence()
-            cal.append((time.perf_counter() - t0) / 3 * 1e3)
-        t = torch.tensor(cal, dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        cal = [float(x) for x in t.tolist()]
-        exchange["mode"] = "compact" if cal[0] <= cal[1] else "allreduce"
-        exchange["calibration_ms"] = {"compact": round(cal[0], 4), "allreduce": round(cal[1], 4)}
-
     # Clock spin-up, untimed and before the warmup: the first ~40 ms of work after the device was idle run on
     # ramping clocks (tools/step_first.py: 1.05 -> 0.90 ms/step over the first 35 steps), and a 5-step warmup ends
     # inside that ramp.  A training run sees the steady state, so that is what the K timed steps should see too.
@@ -514,6 +495,28 @@ def main():
             break
         step(None)
         spin_steps += 1
+    if args.exchange == "auto" and launched and (world > 1 or args.rehearse_calibration) and not forward_only:
+        # which exchange is faster depends on what RCCL makes of this node's xGMI links: measure, don't guess.
+        # Untimed, AFTER the spin-up (on ramping clocks the mode measured second would win) and before the warmup;
+        # the modes alternate (two rounds of one untimed + eight timed steps each), each keeps its best round, and
+        # every rank takes the same decision (MAX over ranks of each time).
+        best = {"compact": float("inf"), "allreduce": float("inf")}
+        for _round in range(2):
+            for mode in ("compact", "allreduce"):
+                exchange["mode"] = mode
+                step(None)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(8):
+                    step(None)
+                fence()
+                best[mode] = min(best[mode], (time.perf_counter() - t0) / 8 * 1e3)
+        t = torch.tensor([best["compact"], best["allreduce"]], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        cal = [float(x) for x in t.tolist()]
+        exchange["mode"] = "compact" if cal[0] <= cal[1] else "allreduce"
+        exchange["calibration_ms"] = {"compact": round(cal[0], 4), "allreduce": round(cal[1], 4)}
+
     for _ in range(args.warmup):
         step(None)
     events = []
