@@ -51,12 +51,31 @@ _workspaces: Dict[tuple, torch.Tensor] = {}
 _pinned = {}
 
 
-def _pinned_total(device: torch.device) -> torch.Tensor:
-    t = _pinned.get(device)
-    if t is None:
-        t = torch.zeros(1, dtype=torch.int64).pin_memory()
-        _pinned[device] = t
-    return t
+class _PinnedSlot:
+    """One pinned int64 the sort's scan kernel stores the pair count into.  A slot belongs to ONE sort from its launch
+    until the host has read the count: two renders in flight on a device (render(defer_count=True) twice before the
+    first render_backward, or an evaluation render between a deferred render and its backward) must not share the
+    word - the later sort would overwrite the count the earlier one is still to be judged by."""
+
+    def __init__(self, tensor, pool):
+        self.tensor, self._pool = tensor, pool
+
+    def release(self):
+        if self._pool is not None:
+            pool, self._pool = self._pool, None
+            pool.append(self.tensor)
+
+    def __del__(self):                      # a PendingSort dropped without finish(): the word goes back to the pool
+        try:
+            self.release()
+        except Exception:                   # interpreter shutdown
+            pass
+
+
+def _pinned_total(device: torch.device) -> "_PinnedSlot":
+    """A free pinned pair-count word of `device` (a new one if all are held by sorts whose count is unread)."""
+    pool = _pinned.setdefault(device, [])
+    return _PinnedSlot(pool.pop() if pool else torch.zeros(1, dtype=torch.int64).pin_memory(), pool)
 
 
 def _workspace(device: torch.device, nbytes: int, kind: str = "n") -> torch.Tensor:
@@ -167,7 +186,8 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
     i32 = dict(dtype=torch.int32, device=dev)
     tile_ranges = torch.empty((num_tiles, 2), **i32)
     st = _stream(dev)
-    total = _pinned_total(dev)                  # pinned: the 8-byte read-back is a single DMA
+    slot = _pinned_total(dev)                   # pinned: the 8-byte read-back is a single DMA
+    total = slot.tensor
     total[0] = 0
     tiles_c = tiles_touched.contiguous().to(torch.int32)
     means_c, depths_c, radii_c = means_2d.contiguous(), depths.contiguous(), radii.contiguous()
@@ -177,6 +197,7 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
                                         int(img_h), _ptr(ws), ws.numel(),
                                         C.cast(total.data_ptr(), C.POINTER(C.c_int64)), st), "cugs_sort_count_pairs")
     p = int(total[0])
+    slot.release()
     keys = torch.empty((p if want_keys else 0,), dtype=torch.int64, device=dev)
     vals = torch.empty((p,), **i32)
     if num_tiles > 0:
@@ -221,14 +242,15 @@ class PendingSort:
     valid the prediction was too small and everything launched on these buffers must be redone with the
     returned (exact) SortingOutput."""
 
-    def __init__(self, args, keys, vals, tile_ranges, capacity, total, event):
+    def __init__(self, args, keys, vals, tile_ranges, capacity, slot, event):
         self._args, self._keys, self._vals, self.tile_ranges = args, keys, vals, tile_ranges
-        self.capacity, self._total, self._event = capacity, total, event
+        self.capacity, self._slot, self._event = capacity, slot, event
         self.gaussian_values_sorted = vals
 
     def finish(self):
         self._event.synchronize()
-        p = int(self._total[0])
+        p = int(self._slot.tensor[0])
+        self._slot.release()                 # the word is this sort's own until here (_PinnedSlot)
         means_2d, depths, radii, tiles, img_w, img_h, want_keys = self._args
         if p == -1:      # a depth outside the range of the three-pass depth sort: the general route decides
             return sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys), False
@@ -263,7 +285,8 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
     means_c, depths_c, radii_c = means_2d.contiguous(), depths.contiguous(), radii.contiguous()
     ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n")
     wp = _workspace(dev, lib.cugs_sort_pair_workspace_bytes(cap), "p")
-    total = _pinned_total(dev)
+    slot = _pinned_total(dev)
+    total = slot.tensor
     check(lib.cugs_sort_pairs_predicted(n, cap, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w),
                                         int(img_h), _ptr(ws), ws.numel(), _ptr(wp), wp.numel(),
                                         _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals), _ptr(tile_ranges),
@@ -271,7 +294,7 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
           "cugs_sort_pairs_predicted")
     ev = torch.cuda.Event()
     ev.record()
-    return PendingSort((means_c, depths_c, radii_c, tiles_c, img_w, img_h, want_keys), keys, vals, tile_ranges, cap, total, ev)
+    return PendingSort((means_c, depths_c, radii_c, tiles_c, img_w, img_h, want_keys), keys, vals, tile_ranges, cap, slot, ev)
 
 
 def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: torch.Tensor,

@@ -852,6 +852,36 @@ def test_deferred_pair_count_render(pkg, orc, dev):
     assert again.total_pairs == ref.total_pairs and torch.equal(again.color, ref.color)
 
 
+def test_two_deferred_renders_in_flight(pkg, orc, dev):
+    """Two render(defer_count=True) calls before the first render_backward (views accumulated before one optimizer
+    step), with a blocking render in between: each sort's pair count arrives in a pinned word of its own, so every
+    output is judged by, and trimmed to, its OWN count - with one word per device the later sort overwrote it."""
+    w, h, deg = 640, 360, 1
+    settings = pkg.RenderSettings(background=[0.0, 0.0, 0.0], active_sh_degree=deg)
+    arr_a, cam = _scene(pkg, 20000, w, h, deg, seed=51, mu_s=-3.9)
+    arr_b, _ = _scene(pkg, 12000, w, h, deg, seed=52, mu_s=-4.4)
+    ma, mb = pkg.scene.to_model(arr_a, dev), pkg.scene.to_model(arr_b, dev)
+    ref_a, ref_b = pkg.render(ma, cam, settings), pkg.render(mb, cam, settings)
+    assert ref_a.total_pairs != ref_b.total_pairs
+    pkg.render(ma, cam, settings)                                # the prediction covers the larger view
+    out_a = pkg.render(ma, cam, settings, defer_count=True)
+    out_b = pkg.render(mb, cam, settings, defer_count=True)
+    mid = pkg.render(mb, cam, settings)                          # blocking, while both counts are unread
+    assert out_a.pending is not None and out_b.pending is not None
+    assert out_a.pending._slot.tensor.data_ptr() != out_b.pending._slot.tensor.data_ptr()
+    out_a.wait(), out_b.wait()
+    assert out_a.total_pairs == ref_a.total_pairs and out_b.total_pairs == ref_b.total_pairs
+    assert mid.total_pairs == ref_b.total_pairs
+    assert torch.equal(out_a.gaussian_indices, ref_a.gaussian_indices)
+    assert torch.equal(out_b.gaussian_indices, ref_b.gaussian_indices)
+    assert torch.equal(out_a.color, ref_a.color) and torch.equal(out_b.color, ref_b.color)
+    # the words went back to the pool: a further render allocates none
+    pool = pkg.rasterizer._pinned[torch.device(dev)]
+    held = len(pool)
+    pkg.render(ma, cam, settings, defer_count=True).wait()
+    assert len(pool) == held
+
+
 @pytest.mark.parametrize("scale", [1.0, 0.02, 5000.0])
 def test_depth_sort_routes(pkg, orc, dev, scale):
     """The depth ordering runs three 9-bit passes on the key's offset from the near plane when every splat that emits
