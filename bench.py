@@ -8,8 +8,8 @@ processes, one GPU each; the parent never touches a GPU); under `python -m torch
 it is one of the ranks.  `n_gpus` in the JSON line is the world size RCCL reports; --gpus != world size is an error.
 
 One "step" = one pass of the hot path over one training view per GPU:
-render() + render_backward() (+ the gradient exchange over RCCL when N > 1: --exchange compact | allreduce |
-auto, the default, which times both before the warm-up and keeps the faster; + FusedAdam.step with --adam /
+render() + render_backward() (+ the gradient exchange over RCCL when N > 1: --exchange compact | compact-early | allreduce |
+auto, the default, which times each after the clock spin-up and keeps the fastest; + FusedAdam.step with --adam /
 config4).  Inputs (parameters, dL_dcolor) are resident in HBM before the timed
 region.  Default workload = BASELINE.json configs[2]: 1 M synthetic Gaussians, 1920x1080, SH
 degree 3 (scene generator: cuda-gaussian-splatting_amd/scene.py).
@@ -146,17 +146,24 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
         if sampled:
             events.append(ev)
         return srt.total_pairs, fwd, pkg.BackwardOutput(None, None, None, None, None, d_means)
-    compact = do_allreduce and exchange == "compact"
+    early = do_allreduce and exchange == "compact-early"
+    compact = do_allreduce and (exchange == "compact" or early)
     gated = torch.empty((n, 3), dtype=torch.float32, device=g.device) if compact else None
     flat = torch.empty((11 * n,), dtype=torch.float32, device=g.device) if compact else None
+    gather = None
+    if early:          # as render_backward(..., on_gated_ready=...): the colour gather starts before the projection backward
+        gather = pkg.parallel.begin_colour_gather(R.gated_colour_grad(rb.grad_accum, proj.colour_gate, out=gated))
     pb = R.project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
                             model.opacities, model.sh_coeffs, proj.radii, cam, deg, settings.scale_modifier,
                             grad_accum=rb.grad_accum, colour_gate=proj.colour_gate, dL_dmeans_2d_out=d_means,
-                            dL_drgb_gated_out=gated, skip_sh_grad=compact, geom_flat=flat)
+                            dL_drgb_gated_out=None if early else gated, skip_sh_grad=compact, geom_flat=flat)
     ev[5].record()
     grads = pkg.BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
                                pb.dL_dsh_coeffs, d_means, geom_flat=flat)
-    if compact:        # all-gather 12 B/G colour grads + all-reduce 44 B/G geometry grads, SH grads rebuilt locally
+    if early:          # geometry all-reduce + SH rebuild; the gather has been travelling under k_project_backward
+        grads = pkg.parallel.finish_exchange(grads, gather, model.positions, deg, int(model.sh_coeffs.shape[2]),
+                                             all_cam_centers=all_centres)
+    elif compact:      # all-gather 12 B/G colour grads + all-reduce 44 B/G geometry grads, SH grads rebuilt locally
         grads = pkg.parallel.exchange_gradients(grads, gated, model.positions, cam.camera_center(), deg,
                                                 int(model.sh_coeffs.shape[2]), all_cam_centers=all_centres)
     elif do_allreduce:   # plain SUM all-reduce of all five tensors (236 B/G)
@@ -383,10 +390,11 @@ def main():
     ap.add_argument("--config", default="config3", choices=["config2", "config3", "config4"])
     ap.add_argument("--adam", action="store_true", help="include FusedAdam.step in the step (implied by config4)")
     ap.add_argument("--mu-s", type=float, default=None, help="override the log-scale mean (dense variant: -3.5)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "compact", "allreduce"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "compact", "compact-early", "allreduce"],
                     help="N>1 gradient exchange: compact = all-gather colour grads + all-reduce geometry grads "
-                         "(SH grads rebuilt locally); allreduce = SUM all-reduce of all five gradient tensors; "
-                         "auto = time three steps of each before the warmup and keep the faster one")
+                         "(SH grads rebuilt locally); compact-early = the same with the colour gather started before "
+                         "the projection backward (it travels under that kernel); allreduce = SUM all-reduce of all "
+                         "five gradient tensors; auto = time each after the spin-up and keep the fastest")
     ap.add_argument("--rehearse-calibration", action="store_true",
                     help="run the auto exchange calibration even with a single rank (one-GPU rehearsal of the N>1 path)")
     ap.add_argument("--spinup-ms", type=float, default=250.0,
@@ -500,9 +508,10 @@ def main():
         # Untimed, AFTER the spin-up (on ramping clocks the mode measured second would win) and before the warmup;
         # the modes alternate (two rounds of one untimed + eight timed steps each), each keeps its best round, and
         # every rank takes the same decision (MAX over ranks of each time).
-        best = {"compact": float("inf"), "allreduce": float("inf")}
+        modes = ("compact", "compact-early", "allreduce")
+        best = {m: float("inf") for m in modes}
         for _round in range(2):
-            for mode in ("compact", "allreduce"):
+            for mode in modes:
                 exchange["mode"] = mode
                 step(None)
                 fence()
@@ -511,11 +520,11 @@ def main():
                     step(None)
                 fence()
                 best[mode] = min(best[mode], (time.perf_counter() - t0) / 8 * 1e3)
-        t = torch.tensor([best["compact"], best["allreduce"]], dtype=torch.float64, device=dev)
+        t = torch.tensor([best[m] for m in modes], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         cal = [float(x) for x in t.tolist()]
-        exchange["mode"] = "compact" if cal[0] <= cal[1] else "allreduce"
-        exchange["calibration_ms"] = {"compact": round(cal[0], 4), "allreduce": round(cal[1], 4)}
+        exchange["mode"] = modes[min(range(len(modes)), key=lambda i: cal[i])]      # ties: the earlier mode
+        exchange["calibration_ms"] = {m: round(c_, 4) for m, c_ in zip(modes, cal)}
 
     for _ in range(args.warmup):
         step(None)

@@ -77,6 +77,7 @@ SIGNATURES = {
     "cugs_project_backward_adam": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Camera), _F, _P,
                                         C.POINTER(AdamFused), _P, _P]),
     "cugs_sh_backward_views": (_I, [_I, _L, _I, _P, _I, _P, C.POINTER(C.c_float), _P, _P]),
+    "cugs_gated_colour_grad": (_I, [_L, _P, _P, _P, _P]),
     "cugs_adam_bias_correction": (None, [_F, _F, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cugs_fused_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
     "cugs_fused_adam_groups": (_I, [C.POINTER(AdamGroup), _I, _F, _F, _F, _F, _F, _P]),

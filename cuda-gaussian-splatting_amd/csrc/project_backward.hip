@@ -406,6 +406,22 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     if (p.d_means_out) { p.d_means_out[idx * 2 + 0] = g_mx; p.d_means_out[idx * 2 + 1] = g_my; }
 }
 
+// ---- the gated colour gradient on its own (data-parallel exchange, early gather) ----
+// out[i][ch] = grad_accum[i][ch] * gate bit ch of colour_gate[i]: exactly what k_project_backward writes to
+// dL_drgb_gated_out, available as soon as the backward blend has finished - the all-gather of these 12 B/Gaussian
+// can then run UNDER the projection backward instead of after it.  Reads one 16-byte chunk of each 64-byte row.
+__global__ __launch_bounds__(CUGS_BLOCK) void k_gated_colour_grad(int64_t n, const float* __restrict__ grad_accum,
+                                                                  const uint8_t* __restrict__ colour_gate,
+                                                                  float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * CUGS_BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const float4 r0 = *reinterpret_cast<const float4*>(grad_accum + idx * CUGS_GRAD_STRIDE);
+    const unsigned gate = colour_gate[idx];
+    out[idx * 3 + 0] = r0.x * ((gate & 1u) ? 1.0f : 0.0f);             // sh_backward.cu:99-100
+    out[idx * 3 + 1] = r0.y * ((gate & 2u) ? 1.0f : 0.0f);
+    out[idx * 3 + 2] = r0.z * ((gate & 4u) ? 1.0f : 0.0f);
+}
+
 // ---- standalone SH backward (evaluate_sh_backward_cuda, core/sh_backward.cu:114-156) ----
 template <int C, bool ALIGNED>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_sh_backward(int64_t n, int degree, const float* __restrict__ sh,
@@ -580,7 +596,7 @@ extern "C" int cugs_project_backward(int64_t n, int num_coeffs, int active_degre
     if (!positions || !rotations || !scales || !opacities || !radii || !dL_dpositions || !dL_drotations ||
         !dL_dscales || !dL_dopacities)
         return CUGS_EINVAL;
-    if (!dL_dsh_coeffs && !dL_drgb_gated_out) return CUGS_EINVAL;   // one of the two colour-gradient outputs
+    // dL_dsh_coeffs and dL_drgb_gated_out both NULL: geometry gradients only (cugs_gated_colour_grad took the colour half)
     if (!colour_gate && !sh_coeffs) return CUGS_EINVAL;
     if (!grad_accum && (!dL_dmeans_2d || !dL_dcov_2d_inv || !dL_drgb || !dL_dopacity_act)) return CUGS_EINVAL;
     if (grad_accum && !cugs_aligned16(grad_accum)) return CUGS_EALIGN;
@@ -678,4 +694,16 @@ extern "C" int cugs_sh_backward_views(int degree, int64_t n, int num_coeffs, con
         case 9: return launch_shv<9>(n, degree, positions, gated_rgb_views, vc, dL_dsh, aligned, st);
         default: return launch_shv<16>(n, degree, positions, gated_rgb_views, vc, dL_dsh, aligned, st);
     }
+}
+
+extern "C" int cugs_gated_colour_grad(int64_t n, const float* grad_accum, const uint8_t* colour_gate,
+                                      float* dL_drgb_gated_out, void* stream) {
+    if (n < 0) return CUGS_EINVAL;
+    if (n == 0) return 0;
+    if (!grad_accum || !colour_gate || !dL_drgb_gated_out) return CUGS_EINVAL;
+    if (!cugs_aligned16(grad_accum)) return CUGS_EALIGN;
+    hipLaunchKernelGGL(k_gated_colour_grad, dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, static_cast<hipStream_t>(stream), n,
+                       grad_accum, colour_gate, dL_drgb_gated_out);
+    CUGS_LAUNCH_CHECK();
+    return 0;
 }

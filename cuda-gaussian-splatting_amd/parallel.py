@@ -102,6 +102,65 @@ def exchange_gradients(grads: BackwardOutput, gated_rgb: torch.Tensor, positions
     return grads
 
 
+# --------------------------------------------------------------------------------------
+# Compact exchange with the colour gather started EARLY: the gated colour gradient is complete when the backward
+# blend is (it is the blend's dL_drgb times the projection's gate bits, cugs_gated_colour_grad), one kernel
+# before the geometry gradients exist.  begin_colour_gather() puts the all-gather - half of the exchange's bytes -
+# on the wire at that point (render_backward(..., on_gated_ready=...)), so it travels under k_project_backward;
+# finish_exchange() then all-reduces the geometry gradients and rebuilds the SH gradient as exchange_gradients does.
+# Same collectives in the same order on the communicator, same bits.
+# --------------------------------------------------------------------------------------
+class ColourGather:
+    """Handle of a colour gather in flight: `views` [V*N,3] (rank order), `centres` [V*3] or None, work handles."""
+
+    def __init__(self, views, centres, works, world, n):
+        self.views, self.centres, self.works, self.world, self.n = views, centres, works, world, n
+
+
+def begin_colour_gather(gated_rgb: torch.Tensor, cam_center: Optional[torch.Tensor] = None,
+                        group: Optional[dist.ProcessGroup] = None) -> ColourGather:
+    """Starts the all-gather of this rank's [N,3] gated colour gradient (and of its camera centre when given) and
+    returns at once.  Without a process group the "gather" is the tensor itself."""
+    n = int(gated_rgb.shape[0])
+    if not dist.is_initialized():
+        return ColourGather(gated_rgb.reshape(n, 3), cam_center.reshape(3) if cam_center is not None else None, [], 1, n)
+    world = dist.get_world_size(group)
+    views = torch.empty((world * n, 3), dtype=gated_rgb.dtype, device=gated_rgb.device)
+    works = [dist.all_gather_into_tensor(views, gated_rgb.reshape(n, 3).contiguous(), group=group, async_op=True)]
+    centres = None
+    if cam_center is not None:
+        centres = torch.empty((world * 3,), dtype=cam_center.dtype, device=cam_center.device)
+        works.append(dist.all_gather_into_tensor(centres, cam_center.reshape(3).contiguous(), group=group, async_op=True))
+    return ColourGather(views, centres, works, world, n)
+
+
+def finish_exchange(grads: BackwardOutput, gather: ColourGather, positions: torch.Tensor, active_sh_degree: int,
+                    num_coeffs: int, group: Optional[dist.ProcessGroup] = None, all_cam_centers=None,
+                    rebuild=None) -> BackwardOutput:
+    """Second half of the early-gather exchange: SUM all-reduce of the geometry gradients (in place; one collective
+    when they are views of `grads.geom_flat`), the SH gradient rebuilt from the gathered views underneath it.
+    `all_cam_centers` ([V,3] host values) or the centres gathered by begin_colour_gather(cam_center=...) supply the
+    view directions.  `rebuild` (tests on CPU): replaces rasterizer.sh_backward_views."""
+    geom = [grads.geom_flat] if grads.geom_flat is not None else \
+        [grads.dL_dpositions, grads.dL_dopacities, grads.dL_dscales, grads.dL_drotations]
+    pending = []
+    if dist.is_initialized():
+        pending = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in geom]
+    wait_all(gather.works)
+    if all_cam_centers is not None:
+        host_centres = all_cam_centers
+    else:
+        if gather.centres is None:
+            raise ValueError("finish_exchange: no camera centres (pass all_cam_centers, or cam_center to begin_colour_gather)")
+        host_centres = gather.centres.view(gather.world, 3).cpu().tolist()
+    if rebuild is None:
+        from .rasterizer import sh_backward_views as rebuild
+    grads.dL_dsh_coeffs = rebuild(active_sh_degree, positions, gather.views.view(gather.world, gather.n, 3),
+                                  host_centres, num_coeffs)
+    wait_all(pending)
+    return grads
+
+
 def allreduce_densify_stats(controller, group: Optional[dist.ProcessGroup] = None) -> None:
     """SURVEY §8f N2 under data parallelism: every rank accumulates the densification statistics of its own
     views (DensificationController.accumulate_gradients); before densify() the replicas must agree, so the

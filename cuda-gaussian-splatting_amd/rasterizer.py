@@ -425,6 +425,27 @@ def sh_backward_views(degree: int, positions: torch.Tensor, gated_rgb_views: tor
     return out
 
 
+def gated_colour_grad(grad_accum: torch.Tensor, colour_gate: torch.Tensor,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[N,3] gated colour gradient from the backward blend's accumulator rows and the projection's gate bits
+    (cugs_gated_colour_grad): what project_backward(..., dL_drgb_gated_out=...) writes, available before the
+    projection backward has run (data-parallel exchange: the all-gather starts here)."""
+    _torch_check(grad_accum.is_cuda and grad_accum.dim() == 2 and grad_accum.shape[1] == _lib.GRAD_STRIDE
+                 and grad_accum.is_contiguous() and grad_accum.dtype == torch.float32,
+                 "grad_accum must be a contiguous [N, 16] float32 CUDA tensor")
+    n = int(grad_accum.shape[0])
+    _torch_check(colour_gate is not None and colour_gate.dtype == torch.uint8 and colour_gate.numel() == n,
+                 "colour_gate must be the [N] uint8 gate bits of project_gaussians")
+    if out is None:
+        out = torch.empty((n, 3), dtype=torch.float32, device=grad_accum.device)
+    _torch_check(tuple(out.shape) == (n, 3) and out.is_contiguous() and out.dtype == torch.float32,
+                 "out must be a contiguous [N, 3] float32 tensor")
+    if n > 0:
+        check(lib.cugs_gated_colour_grad(n, _ptr(grad_accum), _ptr(colour_gate.contiguous()), _ptr(out),
+                                         _stream(grad_accum.device)), "cugs_gated_colour_grad")
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # render / render_backward (rasterizer.cpp:22-186)
 # --------------------------------------------------------------------------------------
@@ -479,10 +500,13 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, f
 def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: GaussianModel,
                     camera: CameraInfo, settings: RenderSettings,
                     dL_drgb_gated_out: Optional[torch.Tensor] = None,
-                    geom_flat: Optional[torch.Tensor] = None, fused_adam=None) -> BackwardOutput:
+                    geom_flat: Optional[torch.Tensor] = None, fused_adam=None, on_gated_ready=None) -> BackwardOutput:
     """`dL_drgb_gated_out` ([N,3], optional, not in the reference): when given, the per-view SH gradient
     is NOT materialised (dL_dsh_coeffs is None) and the gated colour gradient is written there instead,
     for parallel.exchange_gradients() to rebuild the summed SH gradient after the all-gather.
+    `on_gated_ready` (callable, optional; needs dL_drgb_gated_out): the gated colour gradient is made right after
+    the backward blend (cugs_gated_colour_grad) and the callable is invoked with it BEFORE the projection backward
+    is queued - parallel.begin_colour_gather starts the all-gather there, which then travels under that kernel.
     `fused_adam` (a FusedAdam built on `model`, optional, not in the reference): single-GPU training - the
     projection backward applies the optimizer step to the model IN PLACE (cugs_project_backward_adam) and the
     five parameter gradients are never materialised (they are None in the result; dL_dmeans_2d is returned).
@@ -519,10 +543,16 @@ def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: Ga
                                              float(settings.scale_modifier), _ptr(rb.grad_accum), C.byref(adam),
                                              _ptr(d_means_2d), _stream(dev)), "cugs_project_backward_adam")
         return BackwardOutput(None, None, None, None, None, d_means_2d)
+    gated_by_projection = dL_drgb_gated_out
+    if on_gated_ready is not None:
+        _torch_check(dL_drgb_gated_out is not None, "on_gated_ready needs dL_drgb_gated_out")
+        _torch_check(render_out.colour_gate is not None, "on_gated_ready needs render()'s colour_gate")
+        on_gated_ready(gated_colour_grad(rb.grad_accum, render_out.colour_gate, out=dL_drgb_gated_out))
+        gated_by_projection = None                       # already made: the projection backward is geometry only
     pb = project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
                           model.opacities, model.sh_coeffs, render_out.radii, camera, active_degree,
                           settings.scale_modifier, grad_accum=rb.grad_accum, colour_gate=render_out.colour_gate,
-                          dL_dmeans_2d_out=d_means_2d, dL_drgb_gated_out=dL_drgb_gated_out,
+                          dL_dmeans_2d_out=d_means_2d, dL_drgb_gated_out=gated_by_projection,
                           skip_sh_grad=dL_drgb_gated_out is not None, geom_flat=geom_flat)
     return BackwardOutput(pb.dL_dpositions, pb.dL_drotations, pb.dL_dscales, pb.dL_dopacities,
                           pb.dL_dsh_coeffs, d_means_2d, geom_flat=geom_flat)

@@ -183,7 +183,8 @@ int cugs_rasterize_backward_prezeroed(int width, int height, const float backgro
  * Gaussian.  dL_dmeans_2d_out ([n,2], may be NULL)
  * receives BackwardOutput::dL_dmeans_2d (rasterizer.cpp:184) when grad_accum is used.
  * dL_dsh_coeffs may be NULL when dL_drgb_gated_out ([n,3]: dL_drgb with the ReLU gate applied) is
- * given instead: the data-parallel exchange (cugs_sh_backward_views) rebuilds the SH gradient from it. */
+ * given instead: the data-parallel exchange (cugs_sh_backward_views) rebuilds the SH gradient from it.
+ * Both NULL: geometry gradients only (the caller took the colour half with cugs_gated_colour_grad). */
 int cugs_project_backward(int64_t n, int num_coeffs, int active_degree,
                           const float* positions, const float* rotations, const float* scales,
                           const float* opacities, const float* sh_coeffs, const int32_t* radii,
@@ -225,6 +226,13 @@ int cugs_project_backward_adam(int64_t n, int num_coeffs, int active_degree, flo
 int cugs_sh_backward_views(int degree, int64_t n, int num_coeffs, const float* positions,
                            int num_views, const float* gated_rgb_views,
                            const float* cam_centers_host, float* dL_dsh, void* stream);
+
+/* dL_drgb_gated_out[i][ch] = grad_accum[i][ch] * (bit ch of colour_gate[i]) - the [n,3] tensor
+ * cugs_project_backward writes to its dL_drgb_gated_out, made from the backward blend's accumulator alone
+ * (sh_backward.cu:92-100 applied to the blend's dL_drgb): the data-parallel exchange starts the all-gather of
+ * these 12 B/Gaussian before the projection backward runs and lets it travel underneath. */
+int cugs_gated_colour_grad(int64_t n, const float* grad_accum, const uint8_t* colour_gate,
+                           float* dL_drgb_gated_out, void* stream);
 
 /* ---- a11: FusedAdam (optimizer/fused_adam.cu:44-76,140-219) -------------------------
  * bc1 = 1/(1-beta1^t), bc2 = 1/(1-beta2^t) computed in double on the host, then float

@@ -57,6 +57,11 @@ def test_argument_validation_without_gpu(pkg):
     bg = (C.c_float * 3)(0, 0, 0)
     assert lib.cugs_rasterize_backward(16, 16, bg, null, null, null, null, null, null, null, null, null, null, 4,
                                        C.c_void_p(0x1004), null, null, null, null, null) == -2
+    # the gated colour gradient on its own (data-parallel early gather)
+    assert lib.cugs_gated_colour_grad(-1, null, null, null, null) == -1
+    assert lib.cugs_gated_colour_grad(0, null, null, null, null) == 0
+    assert lib.cugs_gated_colour_grad(4, null, null, null, null) == -1
+    assert lib.cugs_gated_colour_grad(4, C.c_void_p(0x1004), C.c_void_p(0x2000), C.c_void_p(0x3000), null) == -2
 
 
 def test_bias_correction_matches_oracle(pkg, orc):

@@ -35,6 +35,19 @@ def _worker(rank, world, port, q):
         assert pending == []
         compact = dict(sum_pos=g2.dL_dpositions.numpy(), sum_rot=g2.dL_drotations.numpy(), views=gviews.numpy(),
                        centres=centres.numpy(), **{k: v.numpy() for k, v in mine.items()})
+        # the early-gather form of the same exchange: the colour gather is started first (under the projection
+        # backward on a GPU), the geometry all-reduce and the rebuild follow; views in rank order, centres gathered
+        g3 = pkg.BackwardOutput(None, None, None, None, None, mk(n, 2), geom_flat=mk(11 * n))
+        flat_mine, gated3 = g3.geom_flat.clone(), mk(n, 3)
+        handle = pkg.parallel.begin_colour_gather(gated3, centre)
+        seen = {}
+        def rebuild(deg, positions, views, centres_, num_coeffs):
+            seen.update(deg=deg, views=views.clone(), centres=centres_, num_coeffs=num_coeffs)
+            return views.sum(0)
+        pkg.parallel.finish_exchange(g3, handle, mk(n, 3), 2, 9, rebuild=rebuild)
+        compact.update(e_flat=flat_mine.numpy(), e_sum=g3.geom_flat.numpy(), e_gated=gated3.numpy(),
+                       e_views=seen["views"].numpy(), e_centres=np.array(seen["centres"], dtype=np.float32),
+                       e_sh=g3.dL_dsh_coeffs.numpy(), e_args=(seen["deg"], seen["num_coeffs"]))
         # N2 statistics: per-rank accumulators (CPU tensors stand in for the device arrays) -> SUM / SUM / MAX
         ctrl = pkg.DensificationController(pkg.DensificationConfig(), 5.0)
         ctrl.grad_accum_, ctrl.grad_count_, ctrl.max_radii_2d_ = mk(n).abs(), torch.full((n,), float(rank + 1)), mk(n).abs() * 10
@@ -79,11 +92,32 @@ def test_allreduce_gradients_world2_gloo():
         assert np.array_equal(c["centres"][0], c0["centre"]) and np.array_equal(c["centres"][1], c1["centre"])
         assert np.allclose(c["sum_pos"], c0["pos"] + c1["pos"]) and np.allclose(c["sum_rot"], c0["rot"] + c1["rot"])
     assert np.array_equal(c0["sum_pos"], c1["sum_pos"])
+    for c in (c0, c1):                                 # early gather: same result, whoever started when
+        assert np.array_equal(c["e_views"][0], c0["e_gated"]) and np.array_equal(c["e_views"][1], c1["e_gated"])
+        assert np.array_equal(c["e_centres"][0], c0["centre"]) and np.array_equal(c["e_centres"][1], c1["centre"])
+        assert np.allclose(c["e_sum"], c0["e_flat"] + c1["e_flat"]) and c["e_args"] == (2, 9)
+        assert np.array_equal(c["e_sh"], c0["e_gated"] + c1["e_gated"])
+    assert np.array_equal(c0["e_sum"], c1["e_sum"])
     assert np.array_equal(c0["noise"], c1["noise"]) and c0["noise"].shape == (2, 50, 3) and c0["noise"].std() > 0.5
     assert c0["refused"] is True and c1["refused"] is True
     for c in (c0, c1):                                 # densification statistics agree on every replica
         assert np.allclose(c["acc_out"], c0["acc"] + c1["acc"]) and np.array_equal(c["cnt_out"], c0["cnt"] + c1["cnt"])
         assert np.array_equal(c["rad_out"], np.maximum(c0["rad"], c1["rad"]))
+
+
+def test_early_gather_without_process_group(pkg):
+    """One process, no group: the "gather" is the rank's own tensor, finish_exchange rebuilds from it."""
+    gated, flat = torch.arange(12.0).reshape(4, 3), torch.ones(44)
+    grads = pkg.BackwardOutput(None, None, None, None, None, None, geom_flat=flat)
+    h = pkg.parallel.begin_colour_gather(gated)
+    out = pkg.parallel.finish_exchange(grads, h, torch.zeros(4, 3), 1, 4, all_cam_centers=[[0.0, 0.0, 0.0]],
+                                       rebuild=lambda d, p, v, c, k: v[0] * 2)
+    assert torch.equal(out.dL_dsh_coeffs, gated * 2) and bool((flat == 1).all())
+    try:
+        pkg.parallel.finish_exchange(grads, pkg.parallel.begin_colour_gather(gated), torch.zeros(4, 3), 1, 4)
+        assert False, "no centres: must raise"
+    except ValueError:
+        pass
 
 
 def test_allreduce_is_noop_without_process_group(pkg):

@@ -852,6 +852,69 @@ def test_deferred_pair_count_render(pkg, orc, dev):
     assert again.total_pairs == ref.total_pairs and torch.equal(again.color, ref.color)
 
 
+def test_early_colour_gather_equals_compact_exchange(pkg, orc, dev):
+    """Data-parallel exchange with the colour gather started before the projection backward
+    (render_backward(..., on_gated_ready=...) + parallel.begin_colour_gather / finish_exchange): the gated colour
+    gradient made by cugs_gated_colour_grad from the accumulator rows is the tensor the projection backward writes,
+    bit for bit; geometry gradients and the rebuilt SH gradient equal the compact exchange's; the hook runs BEFORE
+    the projection backward is queued (the geometry buffer is still untouched when it fires)."""
+    n, w, h, deg = 30000, 640, 360, 3
+    arrays, cam = _scene(pkg, n, w, h, deg, seed=61, mu_s=-4.0)
+    settings = pkg.RenderSettings(background=[0.2, 0.1, 0.3], active_sh_degree=deg)
+    model = pkg.scene.to_model(arrays, dev)
+    g = torch.from_numpy(pkg.scene.make_dl_dcolor(w, h, seed=62)).to(dev)
+    centre = cam.camera_center().tolist()
+    # compact exchange (gated gradient written by the projection backward)
+    gated_a, flat_a = torch.empty((n, 3), device=dev), torch.empty((11 * n,), device=dev)
+    ga = pkg.render_backward(g, pkg.render(model, cam, settings), model, cam, settings, dL_drgb_gated_out=gated_a,
+                             geom_flat=flat_a)
+    ga = pkg.parallel.exchange_gradients(ga, gated_a, model.positions, centre, deg, 16, all_cam_centers=[centre])
+    # early gather
+    gated_b = torch.full((n, 3), float("nan"), device=dev)
+    flat_b = torch.full((11 * n,), float("nan"), device=dev)
+    seen = {}
+    def hook(t):
+        seen["same_tensor"] = t.data_ptr() == gated_b.data_ptr()
+        seen["flat_untouched"] = bool(torch.isnan(flat_b).all())          # synchronises: nothing queued behind yet
+        seen["gated"] = t.clone()
+        seen["gather"] = pkg.parallel.begin_colour_gather(t)
+    gb = pkg.render_backward(g, pkg.render(model, cam, settings), model, cam, settings, dL_drgb_gated_out=gated_b,
+                             geom_flat=flat_b, on_gated_ready=hook)
+    assert seen["same_tensor"] and seen["flat_untouched"]
+    assert gb.dL_dsh_coeffs is None
+    gb = pkg.parallel.finish_exchange(gb, seen["gather"], model.positions, deg, 16, all_cam_centers=[centre])
+    # two backward blends of the same frame differ in the last bits (atomic summation order): 1e-5 here, bit
+    # equality on ONE accumulator below
+    close = lambda a, b: float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-30)
+    assert torch.equal(seen["gated"], gated_b) and close(gated_b, gated_a)
+    assert float(gated_a.abs().max()) > 0 and int((gated_a == 0).all(dim=1).sum()) > 0      # gates / culled rows present
+    assert torch.equal((gated_b == 0), (gated_a == 0))
+    assert close(flat_b, flat_a) and close(gb.dL_dsh_coeffs, ga.dL_dsh_coeffs) and close(gb.dL_dmeans_2d, ga.dL_dmeans_2d)
+    # one accumulator, both producers of the gated gradient: the same bits; geometry gradients too
+    out = pkg.render(model, cam, settings)
+    rb = pkg.rasterizer.rasterize_backward(g, out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges,
+                                           out.gaussian_indices, out.final_T, out.n_contrib, w, h, settings.background,
+                                           n, packed=out.packed, unpack=False)
+    early = pkg.rasterizer.gated_colour_grad(rb.grad_accum, out.colour_gate)
+    outs = []
+    for gated_out in (torch.empty((n, 3), device=dev), None):
+        flat = torch.empty((11 * n,), device=dev)
+        pkg.rasterizer.project_backward(None, None, None, None, model.positions, model.rotations, model.scales,
+                                        model.opacities, model.sh_coeffs, out.radii, cam, deg, 1.0,
+                                        grad_accum=rb.grad_accum, colour_gate=out.colour_gate,
+                                        dL_drgb_gated_out=gated_out, skip_sh_grad=True, geom_flat=flat)
+        outs.append((gated_out, flat))
+    assert torch.equal(early, outs[0][0]) and torch.equal(outs[0][1], outs[1][1])
+    # the stage function on its own, and its argument checks
+    rb_acc = torch.randn((100, 16), device=dev)
+    gate = torch.randint(0, 8, (100,), dtype=torch.uint8, device=dev)
+    got = pkg.rasterizer.gated_colour_grad(rb_acc, gate)
+    bits = torch.stack([(gate >> k) & 1 for k in range(3)], dim=1).to(torch.float32)
+    assert torch.equal(got, rb_acc[:, :3] * bits)
+    with pytest.raises(RuntimeError):
+        pkg.rasterizer.gated_colour_grad(rb_acc, gate[:50])
+
+
 def test_two_deferred_renders_in_flight(pkg, orc, dev):
     """Two render(defer_count=True) calls before the first render_backward (views accumulated before one optimizer
     step), with a blocking render in between: each sort's pair count arrives in a pinned word of its own, so every
