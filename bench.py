@@ -547,6 +547,13 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_gpus * wl.width * wl.height * args.steps / elapsed / 1e6
         alg = algorithmic_bytes(wl.n, c, pairs, wl.width, wl.height)
+        fused_adam = use_adam and not launched
+        if fused_adam:
+            # the optimizer step rides in k_project_backward: its stage moves the backward's bytes plus Adam's, minus
+            # the five gradient tensors, which are neither written nor read back (1548 B/Gaussian at C = 16)
+            extra = alg["adam"] - 2 * 4 * (11 + 3 * c) * wl.n
+            alg["project_backward"] += extra
+            alg["frame"] += extra
         stages_ms = {}
         if events:
             for i, name in enumerate(STAGES):
@@ -585,14 +592,23 @@ def main():
             frame = {"algorithmic_bytes": int(alg["frame"]), "gpu_ms": round(gpu_ms, 4), "achieved": round(fach, 1),
                      "unit": "GB/s", "frac_of_8TBs": round(fach / HBM_PEAK_GBS, 4),
                      "frac_of_6.29TBs": round(fach / HBM_MEASURED_GBS, 4)}
-            if use_adam:
-                frame["note"] = "frame = fwd+bwd stages; the optimizer step is fused into project_backward (adds 28*(11+3C)*N - 8*(11+3C)*N bytes there)"
+            if fused_adam:
+                frame["note"] = ("frame = fwd+bwd stages + the optimizer step fused into project_backward "
+                                 "(28*(11+3C)*N - 8*(11+3C)*N bytes on top of SURVEY 8d's A_bwd term, counted)")
+                if dom == "project_backward":
+                    roofline["kernel"] = "project_backward+adam"
             if stages_ms.get("sort", 0.0) > 0.4 * gpu_ms:
                 frame["note"] = ("the sort dominates this workload and SURVEY 8d prices it at the reference's 172 B/pair: the "
                                  "frame fraction is inflated by bytes this build never moves (see roofline.frac_own_bytes)")
         else:
-            roofline = {"bound": "hbm", "kernel": "render(forward only)", "achieved": None, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": None, "traffic": None}
+            # forward only (configs[1]): no per-stage events; the whole render() against SURVEY 8d's A_fwd
+            fwd_bytes = alg["project_forward"] + alg["sort"] + alg["raster_forward"]
+            fach = fwd_bytes / (ms_per_step * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "render(forward only)", "achieved": round(fach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(fach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes": int(fwd_bytes), "ms": round(ms_per_step, 4),
+                        "note": "whole forward frame (projection + sort + blend) over the wall time of a step; the sort term "
+                                "is SURVEY 8d's reference-shaped 172 B/pair"}
             frame = None
         out = {
             "metric": "fwd+bwd Mpixels/s @1080p, 1M Gaussians, SH3" if args.config == "config3"
