@@ -592,6 +592,10 @@ def main():
             frame = {"algorithmic_bytes": int(alg["frame"]), "gpu_ms": round(gpu_ms, 4), "achieved": round(fach, 1),
                      "unit": "GB/s", "frac_of_8TBs": round(fach / HBM_PEAK_GBS, 4),
                      "frac_of_6.29TBs": round(fach / HBM_MEASURED_GBS, 4)}
+            # the same with the sort priced at what THIS build's sort moves (~45 B/pair + 124 B/Gaussian) instead of the
+            # survey's reference-shaped 172 B/pair: the stricter reading of the frame's memory efficiency
+            own = alg["frame"] - alg["sort"] + wl.n * (4 * 16 + 20 + 32 + 8) + pairs * 45.0
+            frame["frac_of_8TBs_sort_at_own_bytes"] = round(own / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             if fused_adam:
                 frame["note"] = ("frame = fwd+bwd stages + the optimizer step fused into project_backward "
                                  "(28*(11+3C)*N - 8*(11+3C)*N bytes on top of SURVEY 8d's A_bwd term, counted)")
