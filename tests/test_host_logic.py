@@ -50,3 +50,21 @@ def test_render_rejects_cpu_model(pkg):
         pkg.render(m, pkg.scene.make_camera(32, 32), pkg.RenderSettings())
     with pytest.raises(RuntimeError, match="not valid"):     # rasterizer.cpp:27
         pkg.render(pkg.GaussianModel(), pkg.scene.make_camera(32, 32), pkg.RenderSettings())
+
+
+def test_bench_algorithmic_bytes_match_survey_8d():
+    """bench.py's per-stage algorithmic bytes are SURVEY 8d's formulas: the worked number there (C = 16:
+    A_fwd + A_bwd = 668 N + 288 P + 40 HW + 8 tiles) and A_adam = 28 (11 + 3C) N."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, c, p, w, h = 1_000_000, 16, 8_376_524, 1920, 1080
+    b = bench.algorithmic_bytes(n, c, p, w, h)
+    tiles = 120 * 68
+    assert b["frame"] == 668 * n + 288 * p + 40 * w * h + 8 * tiles == 3_163_448_192 + 0 * tiles
+    assert b["frame"] == sum(b[k] for k in bench.STAGES)
+    assert b["adam"] == 28 * 59 * n
+    assert b["raster_backward"] == 714_087_824          # the figure the bench line and DESIGN 4.5 quote
