@@ -80,31 +80,34 @@ CUGS_HD float cugs_expf_core(float x) {
 
 /* The exponential of the blend kernels: exp(-q/2) for the quadratic form q >= 0 of a (pixel, Gaussian) pair,
  * clamped below at exp(-6) (alpha = opacity * that < 1/255 there: the pair is skipped whatever the value), q < 0
- * (rounding noise around the centre; the reference skips power > 0) evaluated as q = 0.  Base 2, ten plain vector
- * instructions on gfx950 where the Cody-Waite route above takes fifteen - the blend loops are bound by
- * instruction issue and evaluate this once per (pixel, Gaussian) step:
- *   y = q * (-log2(e)/2), clamped to [-6 log2 e, 0];  t = y + 1.5*2^23 leaves round(y) = n in the low mantissa
- *   bits;  f = y - n in [-1/2, 1/2];  2^f by a degree-5 minimax polynomial with constant term 1 (max rel. error 1.7e-7 in
- *   fp32 Horner form);  2^n enters as n added to the exponent field: bits(p) + (bits(t) << 23), the constant part of
- *   bits(t) << 23 vanishing mod 2^32.
+ * (rounding noise around the centre; the reference skips power > 0) evaluated as q = 0.  Base 2, ten PLAIN vector
+ * instructions on gfx950 (no v_med3 / v_min: those cost 1.6 issue slots) where the Cody-Waite route above takes
+ * fifteen - the blend loops are bound by instruction issue and evaluate this once per (pixel, Gaussian) step:
+ *   u = sat(q / 12): the clamp of the argument to [0, 12] rides on the multiply (v_mul_f32 ... clamp; NaN -> 0);
+ *   y = u * YS, YS = -(log2(e)/2) * 12 = -6 log2 e, is never formed:  t = fma(u, YS, 1.5*2^23) leaves round(y) = n
+ *   in the low mantissa bits;  f = fma(u, YS, -n) = y - n in [-1/2, 1/2] (one rounding of the exact difference);
+ *   2^f by a degree-5 minimax polynomial with constant term 1 (max rel. error 1.7e-7 in fp32 Horner form);  2^n
+ *   enters as n added to the exponent field: bits(p) + (bits(t) << 23), the constant part of bits(t) << 23
+ *   vanishing mod 2^32.
+ * YS is the float nearest -(log2(e)/2) / CUGS_BLEND_KU for the FLOAT CUGS_BLEND_KU = RN(1/12), so that the
+ * representation error of 1/12 cancels instead of adding up.
  * Every operation is a single correctly rounded fp32 operation (or integer), the same on the host and on the
  * device: identical bits, hence identical skip / clamp / termination decisions in the oracle and in the kernels.
  * Against exp(): <= 1e-6 relative over the whole range (tests/test_detmath.py); the reference's CUDA expf is a
  * 2-ulp approximation itself, and the bar on everything downstream is 1e-4. */
-#define CUGS_BLEND_K (-0.72134752044448170368f)        /* -log2(e)/2 */
-#define CUGS_BLEND_YMIN (-8.6561702453337804f)         /* -6 log2(e) */
+#define CUGS_BLEND_KU (0x1.555556p-4f)                 /* RN(1/12) = 0.0833333358168602 */
+#define CUGS_BLEND_YS (-0x1.14ff58p+3f)                /* RN(-(log2(e)/2) / CUGS_BLEND_KU) = -8.656169891357422 */
 CUGS_HD float cugs_blend_exp_q(float q) {
-    float y = q * CUGS_BLEND_K;
+    float u = q * CUGS_BLEND_KU;
 #if defined(__HIP_DEVICE_COMPILE__)
-    y = __builtin_amdgcn_fmed3f(y, CUGS_BLEND_YMIN, 0.0f);
+    u = __builtin_amdgcn_fmed3f(u, 0.0f, 1.0f);        /* folds into the multiply's clamp bit */
 #else
-    y = (y < CUGS_BLEND_YMIN) ? CUGS_BLEND_YMIN : y;
-    y = (y > 0.0f) ? 0.0f : y;
+    u = (u > 0.0f) ? ((u < 1.0f) ? u : 1.0f) : 0.0f;   /* NaN -> 0, as the hardware clamp */
 #endif
     const float magic = 12582912.0f;                   /* 1.5 * 2^23 */
-    float t = y + magic;
+    float t = fmaf(u, CUGS_BLEND_YS, magic);
     float nf = t - magic;
-    float f = y - nf;
+    float f = fmaf(u, CUGS_BLEND_YS, -nf);
     float p = 0x1.5c37d0p-10f;
     p = fmaf(p, f, 0x1.3d01dep-7f);
     p = fmaf(p, f, 0x1.c6b626p-5f);
