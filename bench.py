@@ -96,6 +96,9 @@ def algorithmic_bytes(n, c, p, w, h):
     return b
 
 
+KEY_SORT = True      # --unkeyed-sort: the stage-by-stage route (the sort derives its keys from the projection's arrays)
+
+
 def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt, all_centres=None):
     """One step with a HIP event before/after every stage (events live on torch's current stream,
     which is the stream every kernel of the C ABI is launched on)."""
@@ -109,11 +112,12 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     ev = [torch.cuda.Event(enable_timing=True) if sampled else _NoEvent() for _ in range(len(STAGES) + 1)]
     ev[0].record()
     proj = R.project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs,
-                               cam, deg, settings.scale_modifier)
+                               cam, deg, settings.scale_modifier, key_sort=KEY_SORT)
     ev[1].record()
-    # as in render(): the sort runs on the predicted pair count, the host reads the true one after queueing the blend
+    # as in render(): the projection has keyed the sort's workspace, the sort runs on the predicted pair count, the
+    # host reads the true one after queueing the blend
     srt = R.sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, cam.width, cam.height,
-                                     want_keys=False)
+                                     want_keys=False, keyed_workspace=proj.sort_workspace)
     ev[2].record()
     accum = torch.empty((n, pkg._lib.GRAD_STRIDE), dtype=torch.float32, device=g.device)   # cleared by the forward blend
     blend = lambda s: R.rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
@@ -400,6 +404,8 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=250.0,
                     help="run the step untimed for this long before the warmup so the clocks have left their idle "
                          "state (reported as `spinup` in the JSON line; 0 disables)")
+    ap.add_argument("--unkeyed-sort", action="store_true",
+                    help="A/B: cugs_project_forward + cugs_sort_pairs_predicted instead of their _keyed variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=368,
@@ -408,6 +414,8 @@ def main():
     ap.add_argument("--launcher-dry-run", action="store_true",
                     help="exercise the N-rank launch + rendezvous + one-JSON-line plumbing over gloo, no GPU work")
     args = ap.parse_args()
+    global KEY_SORT
+    KEY_SORT = not args.unkeyed_sort
 
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run / self_launch
     if args.gpus < 1:

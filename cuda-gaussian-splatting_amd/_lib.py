@@ -55,6 +55,8 @@ SIGNATURES = {
     "cugs_error_string": (C.c_char_p, [_I]),
     "cugs_project_forward": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, C.POINTER(Camera), _F,
                                   _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cugs_project_forward_keyed": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, C.POINTER(Camera), _F,
+                                        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cugs_evaluate_sh": (_I, [_I, _L, _I, _P, _P, _P, _P]),
     "cugs_evaluate_sh_backward": (_I, [_I, _L, _I, _P, _P, _P, _P, _P]),
     "cugs_pack_projected": (_I, [_L, _P, _P, _P, _P, _P, _P]),
@@ -64,6 +66,8 @@ SIGNATURES = {
     "cugs_sort_pairs": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P, _P]),
     "cugs_sort_pairs_predicted": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P,
                                        C.POINTER(C.c_int64), _P]),
+    "cugs_sort_pairs_predicted_keyed": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P,
+                                             C.POINTER(C.c_int64), _P]),
     "cugs_rasterize_forward": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
                                     _P, _P, _P, _P]),
     "cugs_rasterize_forward_zero": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,

@@ -63,6 +63,12 @@ static inline CamArgs cugs_make_cam_args(const cugs_camera* c, float scale_modif
     return a;
 }
 
+// Internal (not part of the C ABI): where the sort's N-level workspace keeps the per-Gaussian depth keys, tile
+// rectangles and the range flag of its three-pass depth ordering (sort.hip: SortWsN), for the projection kernel that
+// fills them in passing (cugs_project_forward_keyed).  CUGS_EWORKSPACE if `bytes` is too small for n Gaussians.
+int cugs_sort_key_slots(void* workspace, size_t bytes, int64_t n, int width, int height, uint32_t** keys, int4** rect,
+                        uint32_t** range_flag) __attribute__((visibility("hidden")));
+
 // XCD-aware bijective block remap (cdna_hip_programming.md T1): blocks b and b+8 share an XCD,
 // so give each XCD a contiguous run of work items (neighbouring tiles share Gaussians -> L2 hits).
 __device__ __forceinline__ unsigned cugs_xcd_remap(unsigned bid, unsigned nwg) {

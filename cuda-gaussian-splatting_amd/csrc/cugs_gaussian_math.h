@@ -185,6 +185,36 @@ __device__ __forceinline__ TileRect tile_rect_of(float x, float y, int radius, i
     return r;
 }
 
+// The sort's per-Gaussian record (sort.hip): the depth key and the 16-byte tile rectangle {x0, y0, w | h << 16,
+// tiles_touched}.  One definition for the two producers - k_depth_keys_rect, which reads the projection's outputs back
+// (the stage boundary of sort_gaussians, sorting.cu:115), and k_project_forward, which has them in registers
+// (cugs_project_forward_keyed: render() saves a launch and 40 MB) - so the two routes cannot differ.
+// `tr` is only read when tiles > 0 && radius > 0.  three_pass: the key is the depth's offset from the near plane
+// (sort.hip, RADIX_DEPTH); *out_of_range reports a Gaussian that emits pairs outside that route's range.
+constexpr int CUGS_DEPTH_BITS = 9;
+constexpr uint32_t CUGS_DEPTH_KEY_BASE = 0x3E4CCCCCu;  // float bits of 0.2f, minus one: offsets of visible splats start at 1, 0 = "sorts first"
+constexpr uint32_t CUGS_DEPTH_KEY_SPAN = 1u << (3 * CUGS_DEPTH_BITS);
+struct SortRecord { uint32_t key; int4 rect; };
+__device__ __forceinline__ SortRecord sort_record_of(float depth, int tiles, int radius, TileRect tr, bool three_pass,
+                                                     bool* out_of_range) {
+    uint32_t key = __float_as_uint(depth);
+    int x0 = 0, y0 = 0, w = 0, h = 0;             // w x h = pairs the reference's loops would write
+    if (tiles > 0) {
+        if (radius > 0 && tr.x1 > tr.x0 && tr.y1 > tr.y0) {              // sorting.cu:44-45
+            x0 = tr.x0; y0 = tr.y0; w = tr.x1 - tr.x0; h = tr.y1 - tr.y0;
+        }
+        if (w == 0) key = 0u;                                            // fills nothing: Q12
+    }
+    *out_of_range = false;
+    if (three_pass) {
+        const uint32_t off = key - CUGS_DEPTH_KEY_BASE;                  // wraps for keys below the base
+        const bool emits = tiles > 0 && w > 0;
+        *out_of_range = emits && !(off >= 1u && off < CUGS_DEPTH_KEY_SPAN);
+        key = emits ? min(off, CUGS_DEPTH_KEY_SPAN - 1u) : 0u;           // a Gaussian without pairs may stand anywhere
+    }
+    return SortRecord{key, make_int4(x0, y0, w | (h << 16), tiles > 0 ? tiles : 0)};
+}
+
 // normalize(p - c) with the norm clamped at 1e-8 (projection.cu:278-280)
 __device__ __forceinline__ V3 view_direction(V3 p, const CamArgs& c) {
     float dx = p.x - c.cc[0], dy = p.y - c.cc[1], dz = p.z - c.cc[2];

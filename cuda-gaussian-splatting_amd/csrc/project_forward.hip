@@ -84,6 +84,8 @@ struct ProjPtrs {
     const float* sh;
     float* means_2d; float* depths; float* cov_2d_inv; int32_t* radii; int32_t* tiles_touched;
     float* opacities_act; float* rgb; float* packed; uint8_t* colour_gate;
+    // cugs_project_forward_keyed: the sort's depth keys / tile rectangles / range flag (its N-level workspace), or null
+    uint32_t* sort_keys; int4* sort_rect; uint32_t* sort_range_flag;
 };
 
 template <int C, bool ALIGNED>
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
     float mx = 0.0f, my = 0.0f, depth = 0.0f, opa = 0.0f;
     Sym2 inv{0.0f, 0.0f, 0.0f};
     int radius = 0, tiles = 0;
+    TileRect tr{0, 0, 0, 0};
 
     const M3 W = view_rotation(cam);
     const V3 t = to_camera(cam, W, pos);
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
                 radius = r;
                 const int ntx = (cam.width + CUGS_TILE - 1) / CUGS_TILE;
                 const int nty = (cam.height + CUGS_TILE - 1) / CUGS_TILE;
-                const TileRect tr = tile_rect_of(mx, my, r, cam.width, cam.height, ntx, nty);
+                tr = tile_rect_of(mx, my, r, cam.width, cam.height, ntx, nty);
                 tiles = max((tr.x1 - tr.x0) * (tr.y1 - tr.y0), 0);
             }
         }
@@ -171,6 +174,14 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
     p.radii[idx] = radius;
     p.tiles_touched[idx] = tiles;
     p.opacities_act[idx] = opa;
+    if (p.sort_keys) {                                                 // kernel-uniform
+        // what k_depth_keys_rect (sort.hip) would make of the four stores above, while they are still in registers
+        bool bad;
+        const SortRecord rec = sort_record_of(depth, tiles, radius, tr, true, &bad);
+        if (bad) atomicOr(p.sort_range_flag, 1u);
+        p.sort_keys[idx] = rec.key;
+        p.sort_rect[idx] = rec.rect;
+    }
     if (ALIGNED && count == CUGS_BLOCK && p.packed) {
         // Full workgroup, 16-byte aligned outputs: the 12-byte-strided rgb / cov rows and the 48-byte packed
         // records are transposed through LDS (the SH tile is dead by now) and leave as contiguous 16-byte
@@ -281,14 +292,15 @@ int launch_sh_forward(int64_t n, int degree, const float* sh, const float* dirs,
 
 }  // namespace
 
-extern "C" int cugs_project_forward(int64_t n, int num_coeffs, int active_degree,
+namespace {
+int project_forward_impl(int64_t n, int num_coeffs, int active_degree,
                                     const float* positions, const float* rotations,
                                     const float* scales, const float* opacities,
                                     const float* sh_coeffs, const cugs_camera* camera_host,
                                     float scale_modifier, float* means_2d, float* depths,
                                     float* cov_2d_inv, int32_t* radii, int32_t* tiles_touched,
                                     float* opacities_act, float* rgb, float* packed, uint8_t* colour_gate,
-                                    void* stream) {
+                                    void* sort_workspace, size_t sort_workspace_bytes, void* stream) {
     if (n < 0 || !camera_host) return CUGS_EINVAL;
     if (active_degree < 0 || active_degree > 3) return CUGS_EINVAL;
     if ((active_degree + 1) * (active_degree + 1) > num_coeffs) return CUGS_EINVAL;
@@ -302,7 +314,12 @@ extern "C" int cugs_project_forward(int64_t n, int num_coeffs, int active_degree
 
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
     ProjPtrs p{positions, rotations, scales, opacities, sh_coeffs, means_2d, depths, cov_2d_inv,
-               radii, tiles_touched, opacities_act, rgb, packed, colour_gate};
+               radii, tiles_touched, opacities_act, rgb, packed, colour_gate, nullptr, nullptr, nullptr};
+    if (sort_workspace) {
+        int rc = cugs_sort_key_slots(sort_workspace, sort_workspace_bytes, n, camera_host->width, camera_host->height,
+                                     &p.sort_keys, &p.sort_rect, &p.sort_range_flag);
+        if (rc) return rc;
+    }
     const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rotations) && cugs_aligned16(rgb) &&
                          cugs_aligned16(cov_2d_inv) && (reinterpret_cast<uintptr_t>(means_2d) & 7u) == 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -312,6 +329,34 @@ extern "C" int cugs_project_forward(int64_t n, int num_coeffs, int active_degree
         case 9: return launch_project<9>(n, active_degree, cam, p, aligned, st);
         default: return launch_project<16>(n, active_degree, cam, p, aligned, st);
     }
+}
+}  // namespace
+
+extern "C" int cugs_project_forward(int64_t n, int num_coeffs, int active_degree,
+                                    const float* positions, const float* rotations,
+                                    const float* scales, const float* opacities,
+                                    const float* sh_coeffs, const cugs_camera* camera_host,
+                                    float scale_modifier, float* means_2d, float* depths,
+                                    float* cov_2d_inv, int32_t* radii, int32_t* tiles_touched,
+                                    float* opacities_act, float* rgb, float* packed, uint8_t* colour_gate,
+                                    void* stream) {
+    return project_forward_impl(n, num_coeffs, active_degree, positions, rotations, scales, opacities, sh_coeffs,
+                                camera_host, scale_modifier, means_2d, depths, cov_2d_inv, radii, tiles_touched,
+                                opacities_act, rgb, packed, colour_gate, nullptr, 0, stream);
+}
+
+extern "C" int cugs_project_forward_keyed(int64_t n, int num_coeffs, int active_degree,
+                                          const float* positions, const float* rotations,
+                                          const float* scales, const float* opacities,
+                                          const float* sh_coeffs, const cugs_camera* camera_host,
+                                          float scale_modifier, float* means_2d, float* depths,
+                                          float* cov_2d_inv, int32_t* radii, int32_t* tiles_touched,
+                                          float* opacities_act, float* rgb, float* packed, uint8_t* colour_gate,
+                                          void* sort_workspace, size_t sort_workspace_bytes, void* stream) {
+    if (!sort_workspace) return CUGS_EINVAL;
+    return project_forward_impl(n, num_coeffs, active_degree, positions, rotations, scales, opacities, sh_coeffs,
+                                camera_host, scale_modifier, means_2d, depths, cov_2d_inv, radii, tiles_touched,
+                                opacities_act, rgb, packed, colour_gate, sort_workspace, sort_workspace_bytes, stream);
 }
 
 extern "C" int cugs_evaluate_sh(int degree, int64_t n, int num_coeffs, const float* sh_coeffs,

@@ -33,9 +33,7 @@ constexpr int RADIX = 256;
 // [0.2, 13 107) spans 2^27 patterns.  A kernel boundary costs ~5 us on this part and a pass is three kernels.  The key
 // kernel checks the range of every Gaussian that emits pairs; a view outside it is reported through the pair count
 // (-1: "redo") and takes the four-pass route on the raw bits.
-constexpr int RADIX_DEPTH = 512, DEPTH_BITS = 9;
-constexpr uint32_t DEPTH_KEY_BASE = 0x3E4CCCCCu;  // float bits of 0.2f, minus one: offsets of visible splats start at 1, 0 = "sorts first"
-constexpr uint32_t DEPTH_KEY_SPAN = 1u << (3 * DEPTH_BITS);
+constexpr int RADIX_DEPTH = 512, DEPTH_BITS = CUGS_DEPTH_BITS;      // key range and base: cugs_gaussian_math.h (sort_record_of)
 constexpr int IPT = 16;                           // items per thread
 constexpr int CHUNK_MIN = CUGS_BLOCK * IPT;       // 4096 items per workgroup: depth sort; sizes the histogram buffers
 #ifndef CUGS_PAIR_CHUNK_MULT
@@ -161,25 +159,15 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_depth_keys_rect(uint32_t n, cons
                                                                 uint32_t* __restrict__ range_flag) {
     const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
     if (i >= n) return;
-    uint32_t key = __float_as_uint(depths[i]);
     const int t = tiles[i];
-    int x0 = 0, y0 = 0, w = 0, h = 0;             // w x h = pairs the reference's loops would write
-    if (t > 0) {
-        const int radius = radii[i];
-        if (radius > 0) {                                                // sorting.cu:44-45
-            const TileRect tr = tile_rect_of(means_2d[i * 2 + 0], means_2d[i * 2 + 1], radius, img_w, img_h, ntx, nty);
-            if (tr.x1 > tr.x0 && tr.y1 > tr.y0) { x0 = tr.x0; y0 = tr.y0; w = tr.x1 - tr.x0; h = tr.y1 - tr.y0; }
-        }
-        if (w == 0) key = 0u;                                            // fills nothing: Q12
-    }
-    if (range_flag) {                                                    // three-pass route: offset from the near plane
-        const uint32_t off = key - DEPTH_KEY_BASE;                       // wraps for keys below the base
-        const bool emits = t > 0 && w > 0;
-        if (emits && !(off >= 1u && off < DEPTH_KEY_SPAN)) atomicOr(range_flag, 1u);
-        key = emits ? min(off, DEPTH_KEY_SPAN - 1u) : 0u;                // a Gaussian without pairs may stand anywhere
-    }
-    keys[i] = key;
-    rect[i] = make_int4(x0, y0, w | (h << 16), t > 0 ? t : 0);
+    const int radius = t > 0 ? radii[i] : 0;
+    TileRect tr{0, 0, 0, 0};
+    if (t > 0 && radius > 0) tr = tile_rect_of(means_2d[i * 2 + 0], means_2d[i * 2 + 1], radius, img_w, img_h, ntx, nty);
+    bool bad;
+    const SortRecord r = sort_record_of(depths[i], t, radius, tr, range_flag != nullptr, &bad);
+    if (bad) atomicOr(range_flag, 1u);
+    keys[i] = r.key;
+    rect[i] = r.rect;
 }
 
 // Pair-level kernels take their item count either exactly (dev_count == nullptr: `count`) or, for the
@@ -986,14 +974,17 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
 // outside that range the totals say so (k_scan_blocksums) and the caller runs this again with three_pass = false.
 int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const float* depths, const int32_t* radii,
                 const int32_t* tiles_touched, int width, int height, int ntx, int nty, hipStream_t st,
-                unsigned long long* total_mapped = nullptr, bool three_pass = true) {
+                unsigned long long* total_mapped = nullptr, bool three_pass = true, bool prekeyed = false) {
     uint32_t* range_flag = reinterpret_cast<uint32_t*>(ws.total) + 6;
     int rc;
     if (three_pass) {
         // (1) stable sort of the Gaussians by depth: keys -> dkey[0], three passes [0] -> [1] -> [0] -> [1]
-        hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
-                           means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[0], ws.rect[0], range_flag);
-        CUGS_LAUNCH_CHECK();
+        // prekeyed: cugs_project_forward_keyed has left dkey[0], rect[0] and the range flag in this workspace already
+        if (!prekeyed) {
+            hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
+                               means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[0], ws.rect[0], range_flag);
+            CUGS_LAUNCH_CHECK();
+        }
         if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
         if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
         if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
@@ -1026,6 +1017,18 @@ int sort_pairs_dispatch(int tiles, A... args) {
 }
 
 }  // namespace
+
+int cugs_sort_key_slots(void* workspace, size_t bytes, int64_t n, int width, int height, uint32_t** keys, int4** rect,
+                        uint32_t** range_flag) {
+    if (!workspace || n < 0 || n > 2147483647ll || width < 0 || height < 0) return CUGS_EINVAL;
+    if ((width + CUGS_TILE - 1) / CUGS_TILE > 32767 || (height + CUGS_TILE - 1) / CUGS_TILE > 32767) return CUGS_EOVERFLOW;
+    SortWsN ws = carve_n(workspace, n);
+    if (bytes < ws.bytes) return CUGS_EWORKSPACE;
+    *keys = ws.dkey[0];
+    *rect = ws.rect[0];
+    *range_flag = reinterpret_cast<uint32_t*>(ws.total) + 6;
+    return 0;
+}
 
 extern "C" size_t cugs_sort_workspace_bytes(int64_t n) {
     if (n < 0) return 0;
@@ -1125,11 +1128,12 @@ extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* mean
 // cugs_sort_pairs with the now known count (the N-level workspace still holds the depth order).  The
 // ~45 us the device idles in cugs_sort_count_pairs + cugs_sort_pairs while the host reads the total
 // and launches the rest (3 % of a 1 M-Gaussian 1080p frame) disappear.
-extern "C" int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
-                                         const int32_t* radii, const int32_t* tiles_touched, int width, int height,
-                                         void* workspace, size_t workspace_bytes, void* pair_workspace,
-                                         size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
-                                         int32_t* tile_ranges, int64_t* total_pairs_host, void* stream) {
+namespace {
+int sort_pairs_predicted_impl(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
+                              const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                              void* workspace, size_t workspace_bytes, void* pair_workspace,
+                              size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                              int32_t* tile_ranges, int64_t* total_pairs_host, void* stream, bool prekeyed) {
     if (n < 0 || capacity < 0 || width < 0 || height < 0 || !tile_ranges || !total_pairs_host) return CUGS_EINVAL;
     if (n > 2147483647ll || capacity > 2147483647ll) return CUGS_EOVERFLOW;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1155,7 +1159,8 @@ extern "C" int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const floa
         else
             (void)hipGetLastError();                              // an unregistered pointer is not an error here
     }
-    int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st, mapped);
+    int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st, mapped, true,
+                         prekeyed);
     if (rc) return rc;
     if (!mapped)
         CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -1169,6 +1174,31 @@ extern "C" int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const floa
     return sort_pairs_dispatch(tiles, ws, wp, (uint32_t)n, (uint32_t)capacity, means_2d, depths, radii, tiles_touched,
                                width, height, ntx, nty, keys_sorted, values_sorted, tile_ranges,
                                static_cast<const unsigned long long*>(ws.total), st);
+}
+}  // namespace
+
+extern "C" int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
+                                         const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                                         void* workspace, size_t workspace_bytes, void* pair_workspace,
+                                         size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                                         int32_t* tile_ranges, int64_t* total_pairs_host, void* stream) {
+    return sort_pairs_predicted_impl(n, capacity, means_2d, depths, radii, tiles_touched, width, height, workspace,
+                                     workspace_bytes, pair_workspace, pair_workspace_bytes, keys_sorted, values_sorted,
+                                     tile_ranges, total_pairs_host, stream, false);
+}
+
+// cugs_sort_pairs_predicted for a `workspace` that cugs_project_forward_keyed has filled on this stream, for these very
+// arrays, since the last sort that used it: the per-Gaussian key / rectangle kernel (one launch, 40 MB per million
+// Gaussians) is skipped.  Everything else, the validity rule and the fallback (cugs_sort_count_pairs + cugs_sort_pairs,
+// which rebuild the keys from the arrays) are those of cugs_sort_pairs_predicted.
+extern "C" int cugs_sort_pairs_predicted_keyed(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
+                                               const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                                               void* workspace, size_t workspace_bytes, void* pair_workspace,
+                                               size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                                               int32_t* tile_ranges, int64_t* total_pairs_host, void* stream) {
+    return sort_pairs_predicted_impl(n, capacity, means_2d, depths, radii, tiles_touched, width, height, workspace,
+                                     workspace_bytes, pair_workspace, pair_workspace_bytes, keys_sorted, values_sorted,
+                                     tile_ranges, total_pairs_host, stream, true);
 }
 
 #ifdef CUGS_DEV

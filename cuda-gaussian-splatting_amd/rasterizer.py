@@ -96,8 +96,12 @@ def _workspace(device: torch.device, nbytes: int, kind: str = "n") -> torch.Tens
 def project_gaussians(positions: torch.Tensor, rotations: torch.Tensor, scales: torch.Tensor,
                       opacities: torch.Tensor, sh_coeffs: torch.Tensor, camera: CameraInfo,
                       active_sh_degree: int, scale_modifier: float = 1.0,
-                      want_colour_gate: bool = True) -> ProjectionOutput:
-    """`want_colour_gate` (not in the reference): also produce ProjectionOutput.colour_gate, the three ReLU gate bits
+                      want_colour_gate: bool = True, key_sort: bool = False) -> ProjectionOutput:
+    """`key_sort` (not in the reference; what render() passes): the kernel also leaves the sort's per-Gaussian depth
+    keys and tile rectangles in this device's sort workspace (cugs_project_forward_keyed), and the returned
+    ProjectionOutput carries that workspace as `.sort_workspace`; sort_gaussians_predicted(..., keyed_workspace=) then
+    skips its first kernel.  The sort must be the next user of the workspace on this stream.
+    `want_colour_gate` (not in the reference): also produce ProjectionOutput.colour_gate, the three ReLU gate bits
     per Gaussian the SH backward would otherwise recompute from the coefficients (~7 us per million Gaussians here,
     24 us saved there); a forward-only render does not ask for it."""
     _torch_check(positions.is_cuda, "positions must be on CUDA")
@@ -126,11 +130,18 @@ def project_gaussians(positions: torch.Tensor, rotations: torch.Tensor, scales: 
                  f"Need at least {(active_sh_degree + 1) ** 2} coefficients for degree {active_sh_degree}")
     pos_c, rot_c, scl_c, opa_c, sh_c = map(_f32c, (positions, rotations, scales, opacities, sh_coeffs))
     cam = camera.to_abi()
+    outs = (_ptr(means_2d), _ptr(depths), _ptr(cov_2d_inv), _ptr(radii), _ptr(tiles_touched), _ptr(opacities_act),
+            _ptr(rgb), _ptr(packed), _ptr(colour_gate))
+    if key_sort:
+        ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n")
+        check(lib.cugs_project_forward_keyed(n, num_coeffs, int(active_sh_degree), _ptr(pos_c), _ptr(rot_c),
+                                             _ptr(scl_c), _ptr(opa_c), _ptr(sh_c), C.byref(cam), float(scale_modifier),
+                                             *outs, _ptr(ws), ws.numel(), _stream(dev)), "cugs_project_forward_keyed")
+        return ProjectionOutput(means_2d, depths, cov_2d_inv, radii, tiles_touched, rgb, opacities_act, packed,
+                                colour_gate, sort_workspace=ws)
     check(lib.cugs_project_forward(n, num_coeffs, int(active_sh_degree), _ptr(pos_c), _ptr(rot_c), _ptr(scl_c),
                                    _ptr(opa_c), _ptr(sh_c), C.byref(cam), float(scale_modifier),
-                                   _ptr(means_2d), _ptr(depths), _ptr(cov_2d_inv), _ptr(radii),
-                                   _ptr(tiles_touched), _ptr(opacities_act), _ptr(rgb), _ptr(packed),
-                                   _ptr(colour_gate), _stream(dev)), "cugs_project_forward")
+                                   *outs, _stream(dev)), "cugs_project_forward")
     return ProjectionOutput(means_2d, depths, cov_2d_inv, radii, tiles_touched, rgb, opacities_act, packed,
                             colour_gate)
 
@@ -264,9 +275,12 @@ class PendingSort:
 
 
 def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Tensor,
-                             tiles_touched: torch.Tensor, img_w: int, img_h: int, want_keys: bool = False):
+                             tiles_touched: torch.Tensor, img_w: int, img_h: int, want_keys: bool = False,
+                             keyed_workspace: Optional[torch.Tensor] = None):
     """sort_gaussians with the pair count predicted from the previous call on this device.  Returns a
-    PendingSort, or (no prediction yet / empty input) a finished SortingOutput."""
+    PendingSort, or (no prediction yet / empty input) a finished SortingOutput.
+    `keyed_workspace`: ProjectionOutput.sort_workspace of project_gaussians(..., key_sort=True) for these very arrays
+    and this image size - the sort's key kernel is skipped (cugs_sort_pairs_predicted_keyed)."""
     dev = means_2d.device
     n = int(means_2d.shape[0])
     last = _last_pairs.get(dev)
@@ -283,14 +297,14 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
     vals = torch.empty((cap,), **i32)
     tiles_c = tiles_touched.contiguous().to(torch.int32)
     means_c, depths_c, radii_c = means_2d.contiguous(), depths.contiguous(), radii.contiguous()
-    ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n")
+    ws = keyed_workspace if keyed_workspace is not None else _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n")
     wp = _workspace(dev, lib.cugs_sort_pair_workspace_bytes(cap), "p")
     slot = _pinned_total(dev)
     total = slot.tensor
-    check(lib.cugs_sort_pairs_predicted(n, cap, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w),
-                                        int(img_h), _ptr(ws), ws.numel(), _ptr(wp), wp.numel(),
-                                        _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals), _ptr(tile_ranges),
-                                        C.cast(total.data_ptr(), C.POINTER(C.c_int64)), _stream(dev)),
+    entry = lib.cugs_sort_pairs_predicted_keyed if keyed_workspace is not None else lib.cugs_sort_pairs_predicted
+    check(entry(n, cap, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w), int(img_h), _ptr(ws),
+                ws.numel(), _ptr(wp), wp.numel(), _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals),
+                _ptr(tile_ranges), C.cast(total.data_ptr(), C.POINTER(C.c_int64)), _stream(dev)),
           "cugs_sort_pairs_predicted")
     ev = torch.cuda.Event()
     ev.record()
@@ -473,14 +487,15 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, f
                             torch.empty((0, 2), **i))
     active_degree = min(int(settings.active_sh_degree), model.max_sh_degree())
     proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs,
-                             camera, active_degree, settings.scale_modifier, want_colour_gate=for_backward)
+                             camera, active_degree, settings.scale_modifier, want_colour_gate=for_backward,
+                             key_sort=True)       # the sort below is the next user of this device's sort workspace
     # the backward blend's accumulator, cleared in passing by the forward blend (which leaves HBM idle)
     accum = torch.empty((n, _lib.GRAD_STRIDE), **f) if for_backward else None
     blend = lambda s: rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
                                         s.gaussian_values_sorted, camera.width, camera.height, settings.background,
                                         packed=proj.packed, zero_buf=accum)
     srt = sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, camera.width,
-                                   camera.height, want_keys=False)
+                                   camera.height, want_keys=False, keyed_workspace=proj.sort_workspace)
     fwd = blend(srt)                                     # queued behind the sort; the host has not waited yet
     if defer_count and isinstance(srt, PendingSort):
         return RenderOutput(fwd.color, fwd.final_T, fwd.n_contrib, proj.means_2d, proj.depths, proj.cov_2d_inv,

@@ -135,6 +135,7 @@ class ProjectionOutput:
     opacities_act: torch.Tensor
     packed: Optional[torch.Tensor] = None      # [N,12] scratch for the blend kernels (not in the reference)
     colour_gate: Optional[torch.Tensor] = None # [N] uint8: the SH backward's ReLU gate bits (not in the reference)
+    sort_workspace: Optional[torch.Tensor] = None  # project_gaussians(key_sort=True): the sort workspace it has keyed
 
 
 @dataclass

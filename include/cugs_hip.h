@@ -71,6 +71,21 @@ int cugs_project_forward(int64_t n, int num_coeffs, int active_degree,
                          int32_t* tiles_touched, float* opacities_act, float* rgb,
                          float* packed, uint8_t* colour_gate, void* stream);
 
+/* cugs_project_forward that ALSO leaves the sort's per-Gaussian inputs - the depth key and the tile rectangle
+ * sort_gaussians derives from depths / means_2d / radii / tiles_touched first thing (sorting.cu:37-60, :115-131) -
+ * in `sort_workspace` (the N-level buffer, cugs_sort_workspace_bytes(n)), while they are in registers.  Not in the
+ * reference, whose render() (rasterizer.cpp:58-75) hands the arrays from one stage to the next; this is what a
+ * render() built on this library calls, followed by cugs_sort_pairs_predicted_keyed on the same stream with the same
+ * workspace and camera size.  All outputs of cugs_project_forward are written as well, bit for bit. */
+int cugs_project_forward_keyed(int64_t n, int num_coeffs, int active_degree,
+                               const float* positions, const float* rotations, const float* scales,
+                               const float* opacities, const float* sh_coeffs,
+                               const cugs_camera* camera_host, float scale_modifier,
+                               float* means_2d, float* depths, float* cov_2d_inv, int32_t* radii,
+                               int32_t* tiles_touched, float* opacities_act, float* rgb,
+                               float* packed, uint8_t* colour_gate, void* sort_workspace,
+                               size_t sort_workspace_bytes, void* stream);
+
 /* ---- a4: evaluate_sh_cuda (core/sh.cu:81-123), output NOT clamped ------------------- */
 int cugs_evaluate_sh(int degree, int64_t n, int num_coeffs, const float* sh_coeffs,
                      const float* directions, float* out_rgb, void* stream);
@@ -127,6 +142,16 @@ int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const float* means_2d
                               void* workspace, size_t workspace_bytes, void* pair_workspace,
                               size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
                               int32_t* tile_ranges, int64_t* total_pairs_host, void* stream);
+
+/* cugs_sort_pairs_predicted on a `workspace` that cugs_project_forward_keyed filled for these arrays (same n, same
+ * width x height) on this stream since the last sort that used it: the per-Gaussian key / rectangle launch is
+ * skipped (one kernel and 40 MB per million Gaussians).  Outputs, validity rule and both fallbacks are those of
+ * cugs_sort_pairs_predicted (the fallbacks rebuild the keys from the arrays). */
+int cugs_sort_pairs_predicted_keyed(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
+                                    const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                                    void* workspace, size_t workspace_bytes, void* pair_workspace,
+                                    size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                                    int32_t* tile_ranges, int64_t* total_pairs_host, void* stream);
 
 /* ---- a6: rasterize_forward (forward.cu:180-240, kernel :48-174) ---------------------
  * out_color [H,W,3], out_final_T [H,W], out_n_contrib [H,W] i32.  `packed` may be NULL

@@ -45,6 +45,12 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.cugs_project_forward(*args(10, 5, 1)) == -1
     assert lib.cugs_project_forward(*args(10, 16, 3)) == -1          # null pointers with n > 0
     assert lib.cugs_project_forward(*args(0, 16, 3)) == 0            # n == 0: nothing to do
+    # the keyed variant: a sort workspace is mandatory, and the same argument checks apply before it is touched
+    assert lib.cugs_project_forward_keyed(*args(0, 16, 3)[:-1], null, 0, null) == -1
+    assert lib.cugs_project_forward_keyed(*args(10, 16, 4)[:-1], C.c_void_p(0x1000), 1 << 20, null) == -1
+    assert lib.cugs_project_forward_keyed(*args(0, 16, 3)[:-1], C.c_void_p(0x1000), 1 << 20, null) == 0
+    assert lib.cugs_sort_pairs_predicted_keyed(-1, 0, null, null, null, null, 16, 16, null, 0, null, 0, null, null, null,
+                                               None, null) == -1
     assert lib.cugs_evaluate_sh(5, 1, 16, null, null, null, null) == -1
     assert lib.cugs_evaluate_sh(2, 1, 4, null, null, null, null) == -1
     assert lib.cugs_evaluate_sh(1, 0, 4, null, null, null, null) == 0

@@ -974,3 +974,51 @@ def test_depth_sort_routes(pkg, orc, dev, scale):
         assert np.array_equal(np_(out.gaussian_keys_sorted).view(np.uint64), srt_ref["keys"])
         assert np.array_equal(np_(out.gaussian_values_sorted), srt_ref["values"])
         assert np.array_equal(np_(out.tile_ranges), srt_ref["tile_ranges"])
+
+
+@pytest.mark.parametrize("scale", [1.0, 5000.0])
+def test_projection_keys_the_sort(pkg, orc, dev, scale):
+    """render()'s route: cugs_project_forward_keyed leaves the sort's depth keys / tile rectangles in the sort
+    workspace and cugs_sort_pairs_predicted_keyed skips the key kernel.  The projection's own outputs must not change
+    by a bit, the sort must give the oracle's keys, order and ranges, and a scene whose depths leave the range of the
+    three-pass depth ordering (everything 5000 times farther and larger: the same image) must be reported through the
+    pair count and recovered by the general route, exactly as on the unkeyed path."""
+    n, w, h, deg = 30000, 640, 360, 1
+    arrays, cam = _scene(pkg, n, w, h, deg, seed=43, mu_s=-4.0)
+    arrays = dict(arrays)
+    arrays["positions"] = (arrays["positions"] * np.float32(scale)).astype(np.float32)
+    arrays["scales"] = (arrays["scales"] + np.float32(np.log(scale))).astype(np.float32)
+    ref = oracle_forward(orc, arrays, cam, degree=deg)
+    model = pkg.scene.to_model(arrays, dev)
+    R = pkg.rasterizer
+    margs = (model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, cam, deg)
+    plain = R.project_gaussians(*margs)
+    assert plain.sort_workspace is None
+    d = torch.device(dev)
+    R._last_pairs[d] = ref["total_pairs"]
+    R._held_capacity.pop(d, None)
+    try:
+        keyed = R.project_gaussians(*margs, key_sort=True)
+        pend = R.sort_gaussians_predicted(keyed.means_2d, keyed.depths, keyed.radii, keyed.tiles_touched, w, h,
+                                          want_keys=True, keyed_workspace=keyed.sort_workspace)
+        assert isinstance(pend, R.PendingSort)
+        srt, valid = pend.finish()
+    finally:
+        R._last_pairs.pop(d, None)
+    _assert_projection_equal(keyed, ref)
+    for name in ("means_2d", "depths", "cov_2d_inv", "radii", "tiles_touched", "rgb", "opacities_act", "packed", "colour_gate"):
+        assert torch.equal(getattr(keyed, name), getattr(plain, name)), name
+    in_range = ref["depths"][ref["tiles_touched"] > 0]
+    assert valid == bool(in_range.min() > 0.2 and in_range.max() < 13000.0) == (scale == 1.0)
+    assert srt.total_pairs == ref["total_pairs"] > 0
+    assert np.array_equal(np_(srt.gaussian_keys_sorted).view(np.uint64), ref["keys"])
+    assert np.array_equal(np_(srt.gaussian_values_sorted), ref["values"])
+    assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])
+    # and the whole frame through render(), which takes this route from its second call on a device
+    settings = pkg.RenderSettings(active_sh_degree=deg)
+    for _ in range(2):
+        out = pkg.render(model, cam, settings)
+        assert out.total_pairs == ref["total_pairs"]
+        assert np.array_equal(np_(out.gaussian_indices), ref["values"])
+        assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"])
+        assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32))
