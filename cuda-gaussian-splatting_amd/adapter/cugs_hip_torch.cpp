@@ -50,12 +50,12 @@ torch::Tensor workspace(const torch::Device& dev, size_t bytes, int kind) {     
     return std::get<2>(pool.back());
 }
 
-}  // namespace
-
-ProjectionOutput project_gaussians(const torch::Tensor& positions, const torch::Tensor& rotations,
-                                   const torch::Tensor& scales, const torch::Tensor& opacities,
-                                   const torch::Tensor& sh_coeffs, const cugs_camera& camera,
-                                   int active_sh_degree, float scale_modifier) {
+// key_sort: cugs_project_forward_keyed - the kernel also leaves the sort's depth keys and tile rectangles in this
+// device's N-level sort workspace; the caller's next sort on the stream must be cugs_sort_pairs_predicted_keyed
+ProjectionOutput project_impl(const torch::Tensor& positions, const torch::Tensor& rotations,
+                              const torch::Tensor& scales, const torch::Tensor& opacities,
+                              const torch::Tensor& sh_coeffs, const cugs_camera& camera,
+                              int active_sh_degree, float scale_modifier, bool key_sort) {
     TORCH_CHECK(positions.is_cuda(), "positions must be on CUDA");
     TORCH_CHECK(positions.dim() == 2 && positions.size(1) == 3);
     const int64_t n = positions.size(0);
@@ -72,6 +72,17 @@ ProjectionOutput project_gaussians(const torch::Tensor& positions, const torch::
     if (n == 0) return o;
     auto pos = f32c(positions), rot = f32c(rotations), scl = f32c(scales), opa = f32c(opacities), sh = f32c(sh_coeffs);
     TORCH_CHECK(sh.dim() == 3 && sh.size(0) == n && sh.size(1) == 3, "sh_coeffs must be [N, 3, C]");
+    if (key_sort) {
+        auto ws = workspace(positions.device(), cugs_sort_workspace_bytes(n), 0);
+        check(cugs_project_forward_keyed(n, static_cast<int>(sh.size(2)), active_sh_degree, ptr<float>(pos), ptr<float>(rot),
+                                         ptr<float>(scl), ptr<float>(opa), ptr<float>(sh), &camera, scale_modifier,
+                                         ptr<float>(o.means_2d), ptr<float>(o.depths), ptr<float>(o.cov_2d_inv),
+                                         ptr<int32_t>(o.radii), ptr<int32_t>(o.tiles_touched), ptr<float>(o.opacities_act),
+                                         ptr<float>(o.rgb), ptr<float>(o.packed), ptr<uint8_t>(o.colour_gate), ws.data_ptr(),
+                                         ws.numel(), stream_of(positions)),
+              "cugs_project_forward_keyed");
+        return o;
+    }
     check(cugs_project_forward(n, static_cast<int>(sh.size(2)), active_sh_degree, ptr<float>(pos), ptr<float>(rot),
                                ptr<float>(scl), ptr<float>(opa), ptr<float>(sh), &camera, scale_modifier,
                                ptr<float>(o.means_2d), ptr<float>(o.depths), ptr<float>(o.cov_2d_inv),
@@ -79,6 +90,15 @@ ProjectionOutput project_gaussians(const torch::Tensor& positions, const torch::
                                ptr<float>(o.rgb), ptr<float>(o.packed), ptr<uint8_t>(o.colour_gate), stream_of(positions)),
           "cugs_project_forward");
     return o;
+}
+
+}  // namespace
+
+ProjectionOutput project_gaussians(const torch::Tensor& positions, const torch::Tensor& rotations,
+                                   const torch::Tensor& scales, const torch::Tensor& opacities,
+                                   const torch::Tensor& sh_coeffs, const cugs_camera& camera,
+                                   int active_sh_degree, float scale_modifier) {
+    return project_impl(positions, rotations, scales, opacities, sh_coeffs, camera, active_sh_degree, scale_modifier, false);
 }
 
 SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor& depths, const torch::Tensor& radii,
@@ -273,14 +293,18 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         return o;
     }
     const int degree = std::min(settings.active_sh_degree, max_sh_degree(model.sh_coeffs));
-    auto proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, camera,
-                                  degree, settings.scale_modifier);
+    static thread_local auto& last_pairs = *new std::map<int, int64_t>();
+    const int dev_index = model.positions.device().index();
+    const int num_tiles = ((w + CUGS_TILE - 1) / CUGS_TILE) * ((h + CUGS_TILE - 1) / CUGS_TILE);
+    // with a prediction to sort on, the projection keys the sort's workspace in passing (one launch and 40 MB per million
+    // Gaussians less; the fallbacks below rebuild the keys from the arrays)
+    const bool keyed = last_pairs.count(dev_index) && num_tiles > 0;
+    auto proj = project_impl(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, camera,
+                             degree, settings.scale_modifier, keyed);
     // The sort runs on the pair count predicted from this device's previous frame (cugs_sort_pairs_predicted) and
     // the forward blend is queued behind it before the host looks at the true count: no idle device while the
     // host waits.  A prediction that was too small is detected afterwards and the exact path re-run.
-    static thread_local auto& last_pairs = *new std::map<int, int64_t>();
     static thread_local auto& pinned = *new std::map<int, torch::Tensor>();
-    const int dev_index = model.positions.device().index();
     // the backward blend's accumulator, cleared in passing by the forward blend (issue-bound, HBM idle)
     torch::Tensor accum = for_backward ? torch::empty({n, CUGS_GRAD_STRIDE}, fopt(model.positions)) : torch::Tensor();
     auto blend = [&](const SortingOutput& s) {
@@ -289,7 +313,6 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     };
     SortingOutput srt;
     ForwardOutput fwd;
-    const int num_tiles = ((w + CUGS_TILE - 1) / CUGS_TILE) * ((h + CUGS_TILE - 1) / CUGS_TILE);
     auto known = last_pairs.find(dev_index);
     if (known == last_pairs.end() || num_tiles == 0) {
         srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
@@ -312,10 +335,10 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         srt.gaussian_values_sorted = torch::empty({cap}, iopt(proj.means_2d));
         auto ws = workspace(proj.means_2d.device(), cugs_sort_workspace_bytes(n), 0);
         auto wp = workspace(proj.means_2d.device(), cugs_sort_pair_workspace_bytes(cap), 1);
-        check(cugs_sort_pairs_predicted(n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii),
-                                        ptr<int32_t>(tiles), w, h, ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr,
-                                        ptr<int32_t>(srt.gaussian_values_sorted), ptr<int32_t>(srt.tile_ranges),
-                                        total.data_ptr<int64_t>(), st), "cugs_sort_pairs_predicted");
+        check(cugs_sort_pairs_predicted_keyed(n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii),
+                                              ptr<int32_t>(tiles), w, h, ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr,
+                                              ptr<int32_t>(srt.gaussian_values_sorted), ptr<int32_t>(srt.tile_ranges),
+                                              total.data_ptr<int64_t>(), st), "cugs_sort_pairs_predicted_keyed");
         hipEvent_t ev;
         TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
         TORCH_CHECK(hipEventRecord(ev, static_cast<hipStream_t>(st)) == hipSuccess, "hipEventRecord failed");
