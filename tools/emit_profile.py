@@ -17,6 +17,9 @@ def main():
     lib = pkg._lib.lib
     fn = lib.cugsdbg_emit_profile
     fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_ulonglong)]
+    force = lib.cugsdbg_sort_column_ratio
+    force.restype, force.argtypes = C.c_int, [C.c_int]
+    force(0)                                    # column-ordered emission whatever the pairs-per-Gaussian ratio
     dev = torch.device("cuda:0")
     wl = pkg.scene.CONFIGS["config3"]
     arrays = pkg.scene.make_gaussians(wl.n, wl.width, wl.height, sh_degree=wl.sh_degree, mu_s=mu_s if mu_s is not None else wl.mu_s)
