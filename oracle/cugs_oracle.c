@@ -455,7 +455,7 @@ static inline int eval_alpha(float pxf, float pyf, float mx, float my, float a, 
  * block-wide early exit do not change any pixel's result (a pixel that is `done`
  * ignores later batches), so the restatement walks each pixel's tile list directly.
  * FMA placement contract: C[ch] = fma(weight, rgb[ch], C[ch]); out = fma(T, bg, C). */
-void orc_rasterize_forward_rows(int img_w, int img_h, int row0, int row1, const float bg[3],
+static void rasterize_forward_rows_impl(int nthreads, int img_w, int img_h, int row0, int row1, const float bg[3],
                                 const int32_t* tile_ranges, const int32_t* gaussian_idx,
                                 const float* means_2d, const float* cov_2d_inv, const float* rgb,
                                 const float* opacities, float* out_color, float* out_final_T,
@@ -463,6 +463,9 @@ void orc_rasterize_forward_rows(int img_w, int img_h, int row0, int row1, const 
     int ntx = (img_w + TILE - 1) / TILE;
     const float thr = 1.0f / 255.0f;                       /* forward.cuh:29 */
     (void)img_h;
+    /* every pixel is independent: the OpenMP split over rows (nthreads > 1; full-frame checks at 1080p) cannot change
+     * a bit of the result */
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4) if (nthreads > 1)
     for (int py = row0; py < row1; ++py)
         for (int px = 0; px < img_w; ++px) {
             int tile_id = (py / TILE) * ntx + (px / TILE);
@@ -494,6 +497,25 @@ void orc_rasterize_forward_rows(int img_w, int img_h, int row0, int row1, const 
         }
 }
 
+void orc_rasterize_forward_rows(int img_w, int img_h, int row0, int row1, const float bg[3],
+                                const int32_t* tile_ranges, const int32_t* gaussian_idx,
+                                const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                const float* opacities, float* out_color, float* out_final_T,
+                                int32_t* out_n_contrib) {
+    rasterize_forward_rows_impl(1, img_w, img_h, row0, row1, bg, tile_ranges, gaussian_idx, means_2d, cov_2d_inv, rgb,
+                                opacities, out_color, out_final_T, out_n_contrib);
+}
+
+/* the same rows on `nthreads` host threads (identical bits) */
+void orc_rasterize_forward_rows_mt(int nthreads, int img_w, int img_h, int row0, int row1, const float bg[3],
+                                   const int32_t* tile_ranges, const int32_t* gaussian_idx,
+                                   const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                   const float* opacities, float* out_color, float* out_final_T,
+                                   int32_t* out_n_contrib) {
+    rasterize_forward_rows_impl(nthreads < 1 ? 1 : nthreads, img_w, img_h, row0, row1, bg, tile_ranges, gaussian_idx,
+                                means_2d, cov_2d_inv, rgb, opacities, out_color, out_final_T, out_n_contrib);
+}
+
 void orc_rasterize_forward(int img_w, int img_h, const float bg[3], const int32_t* tile_ranges,
                            const int32_t* gaussian_idx, const float* means_2d,
                            const float* cov_2d_inv, const float* rgb, const float* opacities,
@@ -513,16 +535,12 @@ void orc_rasterize_forward(int img_w, int img_h, const float bg[3], const int32_
  * any fp32 summation of them (tools/fuzz_parity.py uses it to tell summation noise on a cancelling sum from a wrong
  * gradient): sum |drgb_c| (3), sum |dL_dopa|, sum |dpw dx|, sum |dpw dy|, sum |dpw| dx^2, sum |dpw dx dy|,
  * sum |dpw| dy^2 (dpw = dL_dpower), where dL_dopa and dpw enter with the magnitude of the OPERANDS of dL_dalpha. */
-static void rasterize_backward_rows_impl(int img_w, int img_h, int row0, int row1, const float bg[3],
+static void rasterize_backward_accumulate(int img_w, int row0, int row1, const float bg[3],
                                  const int32_t* tile_ranges, const int32_t* gaussian_idx,
                                  const float* means_2d, const float* cov_2d_inv, const float* rgb,
                                  const float* opacities, const float* dL_dcolor,
-                                 const float* final_T, const int32_t* n_contrib, int n_gaussians,
-                                 float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
-                                 float* dL_dcov_2d_inv, double* mag) {
+                                 const float* final_T, const int32_t* n_contrib, double* acc, double* mag) {
     int ntx = (img_w + TILE - 1) / TILE;
-    (void)img_h;
-    double* acc = (double*)calloc((size_t)(n_gaussians > 0 ? n_gaussians : 1) * 9, sizeof(double));
     for (int py = row0; py < row1; ++py)
         for (int px = 0; px < img_w; ++px) {
             int tile_id = (py / TILE) * ntx + (px / TILE);
@@ -584,6 +602,11 @@ static void rasterize_backward_rows_impl(int img_w, int img_h, int row0, int row
                 }
             }
         }
+}
+
+/* the fp64 sums rounded once (see above) */
+static void rasterize_backward_finish(int n_gaussians, const double* acc, float* dL_drgb, float* dL_dopacity_act,
+                                      float* dL_dmeans_2d, float* dL_dcov_2d_inv) {
     for (int g = 0; g < n_gaussians; ++g) {
         const double* A = acc + (size_t)g * 9;
         dL_drgb[g * 3 + 0] = (float)A[0]; dL_drgb[g * 3 + 1] = (float)A[1];
@@ -593,7 +616,73 @@ static void rasterize_backward_rows_impl(int img_w, int img_h, int row0, int row
         dL_dcov_2d_inv[g * 3 + 0] = (float)A[6]; dL_dcov_2d_inv[g * 3 + 1] = (float)A[7];
         dL_dcov_2d_inv[g * 3 + 2] = (float)A[8];
     }
+}
+
+static void rasterize_backward_rows_impl(int img_w, int img_h, int row0, int row1, const float bg[3],
+                                 const int32_t* tile_ranges, const int32_t* gaussian_idx,
+                                 const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                 const float* opacities, const float* dL_dcolor,
+                                 const float* final_T, const int32_t* n_contrib, int n_gaussians,
+                                 float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
+                                 float* dL_dcov_2d_inv, double* mag) {
+    (void)img_h;
+    double* acc = (double*)calloc((size_t)(n_gaussians > 0 ? n_gaussians : 1) * 9, sizeof(double));
+    rasterize_backward_accumulate(img_w, row0, row1, bg, tile_ranges, gaussian_idx, means_2d, cov_2d_inv, rgb, opacities,
+                                  dL_dcolor, final_T, n_contrib, acc, mag);
+    rasterize_backward_finish(n_gaussians, acc, dL_drgb, dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv);
     free(acc);
+}
+
+/* The same rows on `nthreads` host threads (full-frame checks at 1080p).  The rows are cut into BANDS of 64 (a fixed
+ * cut: it does not depend on the thread count); a band is summed in fp64 by one thread in the serial pixel order, and
+ * the bands' tables are added to the total in band order (`omp ordered`) - so the result is the same for every
+ * thread count, and differs from the one-table serial sum only by fp64 association (~1e-16 relative, before the one
+ * rounding to fp32).  Memory: (nthreads + 1) tables of 72 bytes per Gaussian.  Returns 0, or -1 if out of memory. */
+int orc_rasterize_backward_rows_mt(int nthreads, int img_w, int img_h, int row0, int row1, const float bg[3],
+                                   const int32_t* tile_ranges, const int32_t* gaussian_idx,
+                                   const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                   const float* opacities, const float* dL_dcolor,
+                                   const float* final_T, const int32_t* n_contrib, int n_gaussians,
+                                   float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
+                                   float* dL_dcov_2d_inv, double* mag /* optional [n,9], zeroed by the caller */) {
+    (void)img_h;
+    const int BAND = 64;
+    const size_t cells = (size_t)(n_gaussians > 0 ? n_gaussians : 1) * 9;
+    const int nb = row1 > row0 ? (row1 - row0 + BAND - 1) / BAND : 0;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > nb) nthreads = nb > 0 ? nb : 1;
+    double* total = (double*)calloc(cells, sizeof(double));
+    if (!total) return -1;
+    int failed = 0;
+#pragma omp parallel num_threads(nthreads)
+    {
+        double* acc = (double*)calloc(cells, sizeof(double));
+        double* tmag = mag ? (double*)calloc(cells, sizeof(double)) : NULL;
+        if (!acc || (mag && !tmag)) {
+#pragma omp atomic write
+            failed = 1;
+            free(acc);
+            acc = NULL;
+        }
+#pragma omp for ordered schedule(dynamic, 1)
+        for (int b = 0; b < nb; ++b) {
+            const int r0 = row0 + b * BAND, r1 = (r0 + BAND < row1) ? r0 + BAND : row1;
+            if (acc)
+                rasterize_backward_accumulate(img_w, r0, r1, bg, tile_ranges, gaussian_idx, means_2d, cov_2d_inv, rgb,
+                                              opacities, dL_dcolor, final_T, n_contrib, acc, tmag);
+#pragma omp ordered
+            if (acc)
+                for (size_t i = 0; i < cells; ++i) {
+                    if (acc[i] != 0.0) { total[i] += acc[i]; acc[i] = 0.0; }
+                    if (tmag && tmag[i] != 0.0) { mag[i] += tmag[i]; tmag[i] = 0.0; }
+                }
+        }
+        free(acc);
+        free(tmag);
+    }
+    if (!failed) rasterize_backward_finish(n_gaussians, total, dL_drgb, dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv);
+    free(total);
+    return failed ? -1 : 0;
 }
 
 void orc_rasterize_backward_rows(int img_w, int img_h, int row0, int row1, const float bg[3],

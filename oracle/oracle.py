@@ -22,6 +22,7 @@ _lib.orc_position_lr.restype = C.c_float
 _lib.orc_expf.restype = C.c_float
 _lib.orc_expf.argtypes = [C.c_float]
 _lib.orc_project_sh_forward_mt.restype = C.c_int
+_lib.orc_rasterize_backward_rows_mt.restype = C.c_int
 
 TILE = 16
 
@@ -109,7 +110,16 @@ def sort(means_2d, depths, radii, tiles_touched, w, h):
     return dict(keys=keys, values=vals, tile_ranges=ranges, total_pairs=p)
 
 
-def rasterize_forward(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_inv, rgb, opacities, rows=None):
+def host_threads() -> int:
+    """Host threads this process may use (the GPU box gives a one-GPU job a share of its cores)."""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
+def rasterize_forward(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_inv, rgb, opacities, rows=None, threads=1):
+    """`threads` > 1: the rows are spread over host threads (every pixel is independent: identical bits)."""
     bg_a = _f(bg)
     tr, gi = _i(tile_ranges), _i(gidx)
     m, c, r, o = _f(means_2d), _f(cov_2d_inv), _f(rgb), _f(opacities)
@@ -117,13 +127,20 @@ def rasterize_forward(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_inv, rgb, op
     final_T = np.ones((h, w), np.float32)
     n_contrib = np.zeros((h, w), np.int32)
     r0, r1 = (0, h) if rows is None else rows
-    _lib.orc_rasterize_forward_rows(C.c_int(w), C.c_int(h), C.c_int(r0), C.c_int(r1), _p(bg_a), _p(tr), _p(gi),
-                                    _p(m), _p(c), _p(r), _p(o), _p(color), _p(final_T), _p(n_contrib))
+    if threads > 1:
+        _lib.orc_rasterize_forward_rows_mt(C.c_int(threads), C.c_int(w), C.c_int(h), C.c_int(r0), C.c_int(r1), _p(bg_a),
+                                           _p(tr), _p(gi), _p(m), _p(c), _p(r), _p(o), _p(color), _p(final_T),
+                                           _p(n_contrib))
+    else:
+        _lib.orc_rasterize_forward_rows(C.c_int(w), C.c_int(h), C.c_int(r0), C.c_int(r1), _p(bg_a), _p(tr), _p(gi),
+                                        _p(m), _p(c), _p(r), _p(o), _p(color), _p(final_T), _p(n_contrib))
     return dict(color=color, final_T=final_T, n_contrib=n_contrib)
 
 
 def rasterize_backward(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_inv, rgb, opacities, dL_dcolor, final_T,
-                       n_contrib, n, rows=None):
+                       n_contrib, n, rows=None, threads=1):
+    """`threads` > 1: bands of 64 rows summed in fp64 by one thread each and added in band order - the same result
+    for every thread count (orc_rasterize_backward_rows_mt); differs from threads=1 by fp64 association only."""
     bg_a = _f(bg)
     tr, gi = _i(tile_ranges), _i(gidx)
     m, c, r, o = _f(means_2d), _f(cov_2d_inv), _f(rgb), _f(opacities)
@@ -131,6 +148,14 @@ def rasterize_backward(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_inv, rgb, o
     out = dict(dL_drgb=np.empty((n, 3), np.float32), dL_dopacity_act=np.empty(n, np.float32),
                dL_dmeans_2d=np.empty((n, 2), np.float32), dL_dcov_2d_inv=np.empty((n, 3), np.float32))
     r0, r1 = (0, h) if rows is None else rows
+    if threads > 1:
+        rc = _lib.orc_rasterize_backward_rows_mt(C.c_int(threads), C.c_int(w), C.c_int(h), C.c_int(r0), C.c_int(r1),
+                                                 _p(bg_a), _p(tr), _p(gi), _p(m), _p(c), _p(r), _p(o), _p(g), _p(ft),
+                                                 _p(nc), C.c_int(n), _p(out["dL_drgb"]), _p(out["dL_dopacity_act"]),
+                                                 _p(out["dL_dmeans_2d"]), _p(out["dL_dcov_2d_inv"]), None)
+        if rc != 0:
+            raise MemoryError("oracle backward: per-thread accumulator tables do not fit")
+        return out
     _lib.orc_rasterize_backward_rows(C.c_int(w), C.c_int(h), C.c_int(r0), C.c_int(r1), _p(bg_a), _p(tr), _p(gi),
                                      _p(m), _p(c), _p(r), _p(o), _p(g), _p(ft), _p(nc), C.c_int(n),
                                      _p(out["dL_drgb"]), _p(out["dL_dopacity_act"]), _p(out["dL_dmeans_2d"]),
@@ -139,7 +164,7 @@ def rasterize_backward(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_inv, rgb, o
 
 
 def rasterize_backward_magnitudes(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_inv, rgb, opacities, dL_dcolor,
-                                  final_T, n_contrib, n):
+                                  final_T, n_contrib, n, rows=None, threads=1):
     """rasterize_backward plus `mag` [n, 9] (float64): the sums of the MAGNITUDES of the terms of each accumulated
     gradient - sum |drgb_c| (3), sum |dL_dopa|, sum |dpw dx|, sum |dpw dy|, sum |dpw| dx^2, sum |dpw dx dy|,
     sum |dpw| dy^2 - which bound the rounding error of any fp32 evaluation and summation of those terms.  dL_dopa
@@ -152,6 +177,16 @@ def rasterize_backward_magnitudes(w, h, bg, tile_ranges, gidx, means_2d, cov_2d_
     out = dict(dL_drgb=np.empty((n, 3), np.float32), dL_dopacity_act=np.empty(n, np.float32),
                dL_dmeans_2d=np.empty((n, 2), np.float32), dL_dcov_2d_inv=np.empty((n, 3), np.float32),
                mag=np.zeros((n, 9), np.float64))
+    if threads > 1 or rows is not None:
+        r0, r1 = (0, h) if rows is None else rows
+        rc = _lib.orc_rasterize_backward_rows_mt(C.c_int(max(1, threads)), C.c_int(w), C.c_int(h), C.c_int(r0),
+                                                 C.c_int(r1), _p(bg_a), _p(tr), _p(gi), _p(m), _p(c), _p(r), _p(o),
+                                                 _p(g), _p(ft), _p(nc), C.c_int(n), _p(out["dL_drgb"]),
+                                                 _p(out["dL_dopacity_act"]), _p(out["dL_dmeans_2d"]),
+                                                 _p(out["dL_dcov_2d_inv"]), _p(out["mag"]))
+        if rc != 0:
+            raise MemoryError("oracle backward: per-thread accumulator tables do not fit")
+        return out
     _lib.orc_rasterize_backward_magnitudes(C.c_int(w), C.c_int(h), _p(bg_a), _p(tr), _p(gi), _p(m), _p(c), _p(r), _p(o),
                                            _p(g), _p(ft), _p(nc), C.c_int(n), _p(out["dL_drgb"]),
                                            _p(out["dL_dopacity_act"]), _p(out["dL_dmeans_2d"]),
@@ -208,7 +243,7 @@ def blend_exp_q(q: np.ndarray) -> np.ndarray:
 
 # ---- whole pipeline on numpy arrays (what tests compare the GPU against) ----------------
 def render(model: Dict[str, np.ndarray], rotation, translation, fx, fy, cx, cy, w, h, bg=(0.0, 0.0, 0.0),
-           active_degree=3, scale_mod=1.0, rows=None) -> Dict[str, np.ndarray]:
+           active_degree=3, scale_mod=1.0, rows=None, threads=1) -> Dict[str, np.ndarray]:
     """rasterizer.cpp:22-113 on the oracle's stages."""
     vw = view_matrix(rotation, translation)
     cc = (-(np.asarray(rotation, np.float32).T @ np.asarray(translation, np.float32))).astype(np.float32)
@@ -220,19 +255,19 @@ def render(model: Dict[str, np.ndarray], rotation, translation, fx, fy, cx, cy, 
     rgb = clamp_min0(sh_forward(deg, model["sh_coeffs"], dirs))
     srt = sort(proj["means_2d"], proj["depths"], proj["radii"], proj["tiles_touched"], w, h)
     fwd = rasterize_forward(w, h, bg, srt["tile_ranges"], srt["values"], proj["means_2d"], proj["cov_2d_inv"], rgb,
-                            proj["opacities_act"], rows=rows)
+                            proj["opacities_act"], rows=rows, threads=threads)
     out = dict(proj)
     out.update(rgb=rgb, dirs=dirs, view=vw, cam_center=cc, degree=deg, **srt, **fwd)
     return out
 
 
 def render_backward(dL_dcolor, fwd: Dict[str, np.ndarray], model: Dict[str, np.ndarray], fx, fy, cx, cy, w, h,
-                    bg=(0.0, 0.0, 0.0), scale_mod=1.0, rows=None) -> Dict[str, np.ndarray]:
+                    bg=(0.0, 0.0, 0.0), scale_mod=1.0, rows=None, threads=1) -> Dict[str, np.ndarray]:
     """rasterizer.cpp:115-186 on the oracle's stages."""
     n = model["positions"].shape[0]
     rb = rasterize_backward(w, h, bg, fwd["tile_ranges"], fwd["values"], fwd["means_2d"], fwd["cov_2d_inv"],
                             fwd["rgb"], fwd["opacities_act"], dL_dcolor, fwd["final_T"], fwd["n_contrib"], n,
-                            rows=rows)
+                            rows=rows, threads=threads)
     pb = project_backward(model["positions"], model["rotations"], model["scales"], model["opacities"], fwd["view"],
                           fx, fy, cx, cy, scale_mod, fwd["radii"], rb["dL_dmeans_2d"], rb["dL_dcov_2d_inv"],
                           rb["dL_dopacity_act"])

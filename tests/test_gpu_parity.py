@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import max_err_over_max, max_rel_err, np_, oracle_backward, oracle_forward
+from util import blend_stage_report, load_parity, max_err_over_max, max_rel_err, np_, oracle_backward, oracle_forward
 
 pytestmark = pytest.mark.gpu
 
@@ -285,14 +285,21 @@ def test_render_backward_parity(pkg, orc, dev, n, w, h, deg, mu_s, bg, view):
     g = pkg.scene.make_dl_dcolor(w, h)
     grads = pkg.render_backward(torch.from_numpy(g).to(dev), out, model, cam, settings)
     refb = oracle_backward(orc, g, ref, arrays, cam, bg=bg)
-    report = {}
-    for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs", "dL_dmeans_2d"):
+    par = load_parity()
+    names = ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs", "dL_dmeans_2d")
+    rep = par.gradient_report({k: np_(getattr(grads, k)) for k in names}, refb, names)
+    print(par.format_report(rep, "render_backward vs oracle (SURVEY 8d element-wise | of the tensor's scale):"))
+    for name, v in rep["per_tensor"].items():
+        assert v["over_scale"] <= GRAD_TOL, (name, v)    # error relative to the tensor's scale
         got = np_(getattr(grads, name)).reshape(refb[name].shape)
-        report[name] = (max_err_over_max(got, refb[name]), max_rel_err(got, refb[name], floor_frac=1e-3))
-    print(report)
-    for name, (e_max, e_rel) in report.items():
-        assert e_max <= GRAD_TOL, (name, e_max)          # error relative to the tensor's scale
-        assert e_rel <= 20 * GRAD_TOL, (name, e_rel)     # element-wise, floor at 1e-3 of the scale
+        assert max_rel_err(got, refb[name], floor_frac=1e-3) <= 20 * GRAD_TOL, name   # element-wise, floor 1e-3 of scale
+    # SURVEY 8d's own metric (floor 1e-6 of the scale) is printed above; where it exceeds 1e-4 the element must be a
+    # cancelling sum: |diff| within the fp32 bound of the magnitudes of its own terms, shown per accumulator
+    stage = blend_stage_report(pkg, orc, dev, out, ref, g, bg, n, w, h)
+    print(par.format_report(stage, "blend-backward accumulators, element-wise with the magnitude of their terms:"))
+    for name, v in stage.items():
+        assert v["over_scale"] <= GRAD_TOL, (name, v)
+        assert v["over_bar_beyond_term_bound"] == 0, (name, v)
 
 
 def test_rasterize_backward_stage_parity(pkg, orc, dev):
