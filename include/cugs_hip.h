@@ -175,10 +175,16 @@ int cugs_rasterize_forward_zero(int width, int height, const float background_ho
                                 void* zero_buf, size_t zero_bytes, void* stream);
 
 /* ---- a7: rasterize_backward (backward.cu:239-306, kernel :31-233) -------------------
- * grad_accum: [n,CUGS_GRAD_STRIDE] floats, 64-byte aligned scratch (zeroed by the callee);
- * row = {dL_drgb[3], dL_dopacity_act, dL_dmeans_2d[2], dL_dcov_2d_inv[3], 0...}.
- * The four reference-layout outputs (dL_drgb [n,3], dL_dopacity_act [n], dL_dmeans_2d [n,2],
- * dL_dcov_2d_inv [n,3]) are written from it when non-NULL (all four or none). */
+ * grad_accum: [n,CUGS_GRAD_STRIDE] floats, 64-byte aligned scratch (zeroed by the callee).  A row is
+ *   {dL_drgb[3], dL_dopacity_act, M1x, M1y, M2xx, M2xy, M2yy, 0...}
+ * Words 4..8 are NOT gradients: they are the MOMENTS of dL/dpower over the pixel offsets d = pixel centre - mean,
+ *   M1 = sum dL/dpower * (dx, dy),   M2 = sum dL/dpower * (dx^2, dx dy, dy^2),
+ * from which the reference's two tensors follow by a per-Gaussian linear map with Sigma'^-1 = (a, b, c)
+ * (backward.cu:200-213):   dL_dmeans_2d   = (a M1x + b M1y,  b M1x + c M1y)
+ *                          dL_dcov_2d_inv = (-M2xx / 2,  -M2xy,  -M2yy / 2)      [Q3: [1] is the combined off-diagonal]
+ * A C caller that wants gradients must either pass the four reference-layout outputs below (the callee applies the
+ * map: dL_drgb [n,3], dL_dopacity_act [n], dL_dmeans_2d [n,2], dL_dcov_2d_inv [n,3]; all four or none), or hand the
+ * rows to cugs_project_backward / cugs_project_backward_adam, which apply it themselves.  Words 0..3 are final. */
 int cugs_rasterize_backward(int width, int height, const float background_host[3],
                             const int32_t* tile_ranges, const int32_t* gaussian_indices,
                             const float* means_2d, const float* cov_2d_inv, const float* rgb,
@@ -201,9 +207,10 @@ int cugs_rasterize_backward_prezeroed(int width, int height, const float backgro
 
 /* ---- a8+a9: project_backward (projection_backward.cu:253-344, kernel :26-247) -------
  * One launch: k_project_backward + directions + k_evaluate_sh_backward.  The incoming 2-D
- * gradients come either from grad_accum (packed rows, preferred) or, when grad_accum is
- * NULL, from the four reference-layout arrays.  colour_gate ([n] bytes from cugs_project_forward of
- * the same model, camera and degree) supplies the ReLU gate (sh_backward.cu:92-100); when NULL the gate is
+ * gradients come either from grad_accum (the MOMENT rows cugs_rasterize_backward leaves - layout there; the
+ * kernel turns words 4..8 into dL_dmeans_2d / dL_dcov_2d_inv with the Sigma'^-1 it recomputes; preferred) or,
+ * when grad_accum is NULL, from the four reference-layout arrays (which hold gradients, not moments).
+ * colour_gate ([n] bytes from cugs_project_forward of the same model, camera and degree) supplies the ReLU gate (sh_backward.cu:92-100); when NULL the gate is
  * recomputed from sh_coeffs as the reference does - the same bits, 12 num_coeffs more bytes read per
  * Gaussian.  dL_dmeans_2d_out ([n,2], may be NULL)
  * receives BackwardOutput::dL_dmeans_2d (rasterizer.cpp:184) when grad_accum is used.

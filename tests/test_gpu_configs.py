@@ -145,3 +145,57 @@ def test_config4_band_matches_oracle_and_adam_is_bit_exact(pkg, orc, dev, c4):
                 assert np.array_equal(np_(opt.v_[gi][a:b]).reshape(-1).view(np.uint32), v.view(np.uint32)), (pn, step)
     # the step changed the model (a gradient reached the band's Gaussians) and left it finite
     assert bool(torch.isfinite(model.positions).all()) and bool(torch.isfinite(model.sh_coeffs).all())
+
+
+def test_config4_fused_adam_training_steps_equal_the_unfused_path(pkg, dev, monkeypatch):
+    """BASELINE.json configs[3] as a TRAINING step: render -> render_backward(fused_adam=opt) on the 6 M-Gaussian
+    model with the default, non-zero learning rates, two steps (moments carried, bias corrections advancing), against
+    render_backward -> apply_gradients -> step on a twin model - every parameter and moment bit for bit
+    (fused_adam.cu:44-76, 140-164; trainer.cpp:228-242).  The blend backward's atomics may sum in a different order
+    from launch to launch, so the twin's backward is handed the SAME accumulator rows (a copy): everything after the
+    accumulator - the chain rule, the SH gradient tile, the optimizer arithmetic - is what the two paths differ in."""
+    wl = pkg.scene.CONFIGS["config4"]
+    arrays = pkg.scene.make_gaussians(wl.n, wl.width, wl.height, sh_degree=wl.sh_degree)
+    cam = pkg.scene.make_camera(wl.width, wl.height)
+    settings = pkg.RenderSettings(active_sh_degree=wl.sh_degree)
+    g = torch.from_numpy(pkg.scene.make_dl_dcolor(wl.width, wl.height)).to(dev)
+    ma, mb = pkg.scene.to_model(arrays, dev), pkg.scene.to_model(arrays, dev)
+    oa, ob = pkg.FusedAdam(ma), pkg.FusedAdam(mb)
+    assert all(oa.get_lr(pkg.ParamGroup(i)) > 0 for i in range(5))
+    R = pkg.rasterizer
+    real = R.rasterize_backward
+    shared = {}
+
+    def first(*a, **k):                       # path A: the real blend backward; keep a copy of its accumulator rows
+        rb = real(*a, **k)
+        shared["rows"] = rb.grad_accum.clone()
+        return rb
+
+    def second(*a, **k):                      # path B: the same rows instead of a second (re-ordered) atomic sum
+        return pkg.RasterizeBackwardOutput(None, None, None, None, shared.pop("rows"))
+
+    names = ("positions", "sh_coeffs", "opacities", "scales", "rotations")
+    start = ma.positions.clone()
+    for step in (1, 2):
+        out_a = pkg.render(ma, cam, settings)
+        monkeypatch.setattr(R, "rasterize_backward", first)
+        grads = pkg.render_backward(g, out_a, ma, cam, settings)
+        oa.apply_gradients(grads)
+        oa.step()
+        out_b = pkg.render(mb, cam, settings)
+        assert torch.equal(out_a.gaussian_indices, out_b.gaussian_indices)       # twins: the same frame
+        monkeypatch.setattr(R, "rasterize_backward", second)
+        res = pkg.render_backward(g, out_b, mb, cam, settings, fused_adam=ob)
+        monkeypatch.setattr(R, "rasterize_backward", real)
+        assert res.dL_dpositions is None and res.dL_dsh_coeffs is None
+        assert torch.equal(res.dL_dmeans_2d, grads.dL_dmeans_2d)
+        del grads, res, out_a, out_b
+        for i, k in enumerate(names):
+            assert torch.equal(getattr(ma, k), getattr(mb, k)), (step, k)
+            assert torch.equal(oa.m_[i], ob.m_[i]) and torch.equal(oa.v_[i], ob.v_[i]), (step, k)
+        assert oa.step_count_ == ob.step_count_ == step
+    moved = int((ma.positions != start).any(dim=1).sum())
+    assert moved > wl.n // 4                                                     # a real step: the model moved
+    assert bool(torch.isfinite(ma.positions).all()) and bool(torch.isfinite(ma.sh_coeffs).all())
+    del ma, mb, oa, ob
+    torch.cuda.empty_cache()
