@@ -63,6 +63,9 @@ SIGNATURES = {
     "cugs_sort_workspace_bytes": (C.c_size_t, [_L]),
     "cugs_sort_pair_workspace_bytes": (C.c_size_t, [_L]),
     "cugs_sort_count_pairs": (_I, [_L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, C.POINTER(C.c_int64), _P]),
+    "cugs_sort_count_pairs_wide": (_I, [_L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, C.POINTER(C.c_int64), _P]),
+    "cugs_sort_pairs_predicted_wide": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P,
+                                            C.POINTER(C.c_int64), _P]),
     "cugs_sort_pairs": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P, _P]),
     "cugs_sort_pairs_predicted": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P,
                                        C.POINTER(C.c_int64), _P]),

@@ -35,19 +35,38 @@ torch::TensorOptions fopt(const torch::Tensor& like) { return torch::TensorOptio
 torch::TensorOptions iopt(const torch::Tensor& like) { return torch::TensorOptions().dtype(torch::kInt32).device(like.device()); }
 
 // Returns a handle BY VALUE: a reference into the pool would dangle when a later call grows the vector.
-torch::Tensor workspace(const torch::Device& dev, size_t bytes, int kind) {      // grow-only, per device and kind
+// Scratch is per (device, CURRENT STREAM, kind): two renders queued on two streams of one device run concurrently and
+// must not share a sort workspace (cugs_project_forward_keyed writes the sort keys into it).
+torch::Tensor workspace(const torch::Device& dev, size_t bytes, int kind) {      // grow-only
     // intentionally leaked: device tensors must not be destroyed during static destruction, after the
     // HIP caching allocator has gone away
-    static thread_local auto& pool = *new std::vector<std::tuple<torch::Device, int, torch::Tensor>>();
+    static thread_local auto& pool = *new std::vector<std::tuple<torch::Device, void*, int, torch::Tensor>>();
+    void* st = static_cast<void*>(c10::hip::getCurrentHIPStream(dev.index()).stream());
     auto make = [&] { return torch::empty({static_cast<int64_t>(bytes + bytes / 4 + 4096)},
                                           torch::TensorOptions().dtype(torch::kUInt8).device(dev)); };
     for (auto& e : pool)
-        if (std::get<0>(e) == dev && std::get<1>(e) == kind) {
-            if (static_cast<size_t>(std::get<2>(e).numel()) < bytes) std::get<2>(e) = make();
-            return std::get<2>(e);
+        if (std::get<0>(e) == dev && std::get<1>(e) == st && std::get<2>(e) == kind) {
+            if (static_cast<size_t>(std::get<3>(e).numel()) < bytes) std::get<3>(e) = make();
+            return std::get<3>(e);
         }
-    pool.emplace_back(dev, kind, make());
-    return std::get<2>(pool.back());
+    pool.emplace_back(dev, st, kind, make());
+    return std::get<3>(pool.back());
+}
+
+// Host-side state of render()'s predicted sort, one per (device, stream): the running pair-count estimate, the held
+// capacity, the pinned word the count lands in, and how many more sorts stay on the general depth route after one
+// reported a depth outside the three-pass range (-1): sticky, so that such a view does not pay a wasted sort + blend
+// and a blocking re-sort on every frame; probed again after kWideDepthHold sorts.
+struct SortState {
+    int64_t last_pairs = -1;
+    int64_t held_cap = 0;
+    int wide_left = 0;
+    torch::Tensor pinned;
+};
+constexpr int kWideDepthHold = 256;
+SortState& sort_state(const torch::Device& dev) {
+    static thread_local auto& states = *new std::map<std::pair<int, void*>, SortState>();
+    return states[{dev.index(), static_cast<void*>(c10::hip::getCurrentHIPStream(dev.index()).stream())}];
 }
 
 // key_sort: cugs_project_forward_keyed - the kernel also leaves the sort's depth keys and tile rectangles in this
@@ -101,8 +120,9 @@ ProjectionOutput project_gaussians(const torch::Tensor& positions, const torch::
     return project_impl(positions, rotations, scales, opacities, sh_coeffs, camera, active_sh_degree, scale_modifier, false);
 }
 
-SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor& depths, const torch::Tensor& radii,
-                             const torch::Tensor& tiles_touched, int img_w, int img_h) {
+namespace {
+SortingOutput sort_gaussians_impl(const torch::Tensor& means_2d, const torch::Tensor& depths, const torch::Tensor& radii,
+                                  const torch::Tensor& tiles_touched, int img_w, int img_h, bool wide_depth) {
     TORCH_CHECK(means_2d.is_cuda(), "means_2d must be on CUDA");
     const int64_t n = means_2d.size(0);
     const int num_tiles = ((img_w + CUGS_TILE - 1) / CUGS_TILE) * ((img_h + CUGS_TILE - 1) / CUGS_TILE);
@@ -113,9 +133,10 @@ SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor&
     auto m = means_2d.contiguous(), d = depths.contiguous(), r = radii.contiguous();
     auto ws = workspace(means_2d.device(), cugs_sort_workspace_bytes(n), 0);
     int64_t total = 0;
-    if (n > 0)
-        check(cugs_sort_count_pairs(n, ptr<float>(m), ptr<float>(d), ptr<int32_t>(r), ptr<int32_t>(tiles), img_w, img_h,
-                                    ws.data_ptr(), ws.numel(), &total, st), "cugs_sort_count_pairs");
+    if (n > 0)      // wide_depth: the general depth route at once (the caller has seen this view report -1)
+        check((wide_depth ? cugs_sort_count_pairs_wide : cugs_sort_count_pairs)(
+                  n, ptr<float>(m), ptr<float>(d), ptr<int32_t>(r), ptr<int32_t>(tiles), img_w, img_h, ws.data_ptr(),
+                  ws.numel(), &total, st), "cugs_sort_count_pairs");
     o.total_pairs = static_cast<int>(total);
     o.gaussian_keys_sorted = torch::empty({total}, torch::TensorOptions().dtype(torch::kInt64).device(means_2d.device()));
     o.gaussian_values_sorted = torch::empty({total}, iopt(means_2d));
@@ -129,6 +150,12 @@ SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor&
     }
     return o;
 }
+}  // namespace
+
+SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor& depths, const torch::Tensor& radii,
+                             const torch::Tensor& tiles_touched, int img_w, int img_h) {
+    return sort_gaussians_impl(means_2d, depths, radii, tiles_touched, img_w, img_h, false);
+}
 
 ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tensor& cov_2d_inv, const torch::Tensor& rgb,
                                 const torch::Tensor& opacities, const torch::Tensor& tile_ranges,
@@ -139,7 +166,10 @@ ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tens
     o.color = torch::empty({img_h, img_w, 3}, fopt(means_2d));
     o.final_T = torch::empty({img_h, img_w}, fopt(means_2d));
     o.n_contrib = torch::empty({img_h, img_w}, iopt(means_2d));
-    if (img_w == 0 || img_h == 0) return o;
+    if (img_w == 0 || img_h == 0) {
+        if (zero_buf.defined()) zero_buf.zero_();             // the promise holds without a blend launch too
+        return o;
+    }
     auto m = means_2d.contiguous(), c = cov_2d_inv.contiguous(), r = rgb.contiguous(), op = opacities.contiguous();
     auto tr = tile_ranges.contiguous(), gi = gaussian_indices.contiguous();
     if (zero_buf.defined()) {                                   // the blend also clears the backward's accumulator
@@ -293,18 +323,19 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         return o;
     }
     const int degree = std::min(settings.active_sh_degree, max_sh_degree(model.sh_coeffs));
-    static thread_local auto& last_pairs = *new std::map<int, int64_t>();
-    const int dev_index = model.positions.device().index();
+    SortState& state = sort_state(model.positions.device());
     const int num_tiles = ((w + CUGS_TILE - 1) / CUGS_TILE) * ((h + CUGS_TILE - 1) / CUGS_TILE);
+    const bool predicted = state.last_pairs >= 0 && num_tiles > 0;
+    const bool wide = state.wide_left > 0;       // this stream's views leave the three-pass depth range: general route
+    if (wide) --state.wide_left;                 // at 0 the next sort probes the three-pass route again
     // with a prediction to sort on, the projection keys the sort's workspace in passing (one launch and 40 MB per million
-    // Gaussians less; the fallbacks below rebuild the keys from the arrays)
-    const bool keyed = last_pairs.count(dev_index) && num_tiles > 0;
+    // Gaussians less; the fallbacks below, and the general depth route, rebuild the keys from the arrays)
+    const bool keyed = predicted && !wide;
     auto proj = project_impl(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, camera,
                              degree, settings.scale_modifier, keyed);
-    // The sort runs on the pair count predicted from this device's previous frame (cugs_sort_pairs_predicted) and
+    // The sort runs on the pair count predicted from this stream's previous frame (cugs_sort_pairs_predicted) and
     // the forward blend is queued behind it before the host looks at the true count: no idle device while the
     // host waits.  A prediction that was too small is detected afterwards and the exact path re-run.
-    static thread_local auto& pinned = *new std::map<int, torch::Tensor>();
     // the backward blend's accumulator, cleared in passing by the forward blend (issue-bound, HBM idle)
     torch::Tensor accum = for_backward ? torch::empty({n, CUGS_GRAD_STRIDE}, fopt(model.positions)) : torch::Tensor();
     auto blend = [&](const SortingOutput& s) {
@@ -313,32 +344,30 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     };
     SortingOutput srt;
     ForwardOutput fwd;
-    auto known = last_pairs.find(dev_index);
-    if (known == last_pairs.end() || num_tiles == 0) {
-        srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
+    const int64_t prev = state.last_pairs < 0 ? 0 : state.last_pairs;
+    if (!predicted) {
+        srt = sort_gaussians_impl(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h, wide);
         fwd = blend(srt);
     } else {
         // capacity = estimate * 1.10 + 64 Ki, HELD while the estimate drifts below it (down to 80 %) and grown with 5 %
         // to spare: buffer sizes that follow a slowly moving pair count fragment the caching allocator
-        static thread_local auto& held_cap = *new std::map<int, int64_t>();
-        const int64_t needed = std::min<int64_t>(known->second + known->second / 10 + 65536, 2147483647ll);
+        const int64_t needed = std::min<int64_t>(prev + prev / 10 + 65536, 2147483647ll);
         int64_t cap = needed;
-        auto held = held_cap.find(dev_index);
-        if (held != held_cap.end() && needed <= held->second && held->second <= needed + needed / 4) cap = held->second;
-        else if (held != held_cap.end() && needed > held->second) cap = std::min<int64_t>(needed + needed / 20, 2147483647ll);
-        held_cap[dev_index] = cap;
-        if (!pinned.count(dev_index)) pinned[dev_index] = torch::zeros({1}, torch::kInt64).pin_memory();
-        auto total = pinned[dev_index];
+        if (state.held_cap > 0 && needed <= state.held_cap && state.held_cap <= needed + needed / 4) cap = state.held_cap;
+        else if (state.held_cap > 0 && needed > state.held_cap) cap = std::min<int64_t>(needed + needed / 20, 2147483647ll);
+        state.held_cap = cap;
+        if (!state.pinned.defined()) state.pinned = torch::zeros({1}, torch::kInt64).pin_memory();
+        auto total = state.pinned;
         void* st = stream_of(proj.means_2d);
         auto tiles = proj.tiles_touched.contiguous().to(torch::kInt32);
         srt.tile_ranges = torch::empty({num_tiles, 2}, iopt(proj.means_2d));
         srt.gaussian_values_sorted = torch::empty({cap}, iopt(proj.means_2d));
         auto ws = workspace(proj.means_2d.device(), cugs_sort_workspace_bytes(n), 0);
         auto wp = workspace(proj.means_2d.device(), cugs_sort_pair_workspace_bytes(cap), 1);
-        check(cugs_sort_pairs_predicted_keyed(n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii),
-                                              ptr<int32_t>(tiles), w, h, ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr,
-                                              ptr<int32_t>(srt.gaussian_values_sorted), ptr<int32_t>(srt.tile_ranges),
-                                              total.data_ptr<int64_t>(), st), "cugs_sort_pairs_predicted_keyed");
+        check((wide ? cugs_sort_pairs_predicted_wide : cugs_sort_pairs_predicted_keyed)(
+                  n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii), ptr<int32_t>(tiles), w, h,
+                  ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr, ptr<int32_t>(srt.gaussian_values_sorted),
+                  ptr<int32_t>(srt.tile_ranges), total.data_ptr<int64_t>(), st), "cugs_sort_pairs_predicted");
         hipEvent_t ev;
         TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
         TORCH_CHECK(hipEventRecord(ev, static_cast<hipStream_t>(st)) == hipSuccess, "hipEventRecord failed");
@@ -351,22 +380,24 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         if (p >= 0 && p <= cap) {
             srt.total_pairs = static_cast<int>(p);
             srt.gaussian_values_sorted = srt.gaussian_values_sorted.slice(0, 0, p);
-        } else {                                            // prediction too small (or -1: a depth outside the three-pass sort's range): exact path, blend again
-            srt = sort_gaussians(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h);
+        } else {
+            // prediction too small, or -1: a depth outside the three-pass sort's range - remembered for the following
+            // sorts on this stream.  Exact path, blend again.
+            if (p == -1) state.wide_left = kWideDepthHold;
+            srt = sort_gaussians_impl(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h,
+                                      p == -1 || state.wide_left > 0);
             fwd = blend(srt);
         }
     }
     // running maximum with a slow decay: views differ by tens of percent, spare capacity is cheap, a miss is not
-    {
-        const int64_t prev = known == last_pairs.end() ? 0 : known->second;
-        last_pairs[dev_index] = std::max<int64_t>(srt.total_pairs, prev - prev / 32);
-    }
+    state.last_pairs = std::max<int64_t>(srt.total_pairs, prev - prev / 32);
     o.color = fwd.color; o.final_T = fwd.final_T; o.n_contrib = fwd.n_contrib;
     o.means_2d = proj.means_2d; o.depths = proj.depths; o.cov_2d_inv = proj.cov_2d_inv; o.radii = proj.radii;
     o.rgb = proj.rgb; o.opacities_act = proj.opacities_act;
     o.gaussian_indices = srt.gaussian_values_sorted; o.tile_ranges = srt.tile_ranges; o.packed = proj.packed;
     o.colour_gate = proj.colour_gate;
     o.zeroed_accum = accum;
+    if (accum.defined()) o.accum_used = std::make_shared<std::atomic<bool>>(false);
     return o;
 }
 
@@ -396,6 +427,7 @@ BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutpu
     // the accumulator render() had the forward blend clear is good for ONE backward
     torch::Tensor zeroed = ro.zeroed_accum;
     ro.zeroed_accum = torch::Tensor();
+    if (zeroed.defined() && ro.accum_used && ro.accum_used->exchange(true)) zeroed = torch::Tensor();   // a copy used it
     if (zeroed.defined() && (zeroed.dim() != 2 || zeroed.size(0) != n)) zeroed = torch::Tensor();
     auto rb = rasterize_backward(dL_dcolor, ro.means_2d, ro.cov_2d_inv, ro.rgb, ro.opacities_act, ro.tile_ranges,
                                  ro.gaussian_indices, ro.final_T, ro.n_contrib, camera.width, camera.height,

@@ -10,6 +10,9 @@
 
 #include <torch/torch.h>
 
+#include <atomic>
+#include <memory>
+
 #include <array>
 #include <string>
 
@@ -43,8 +46,11 @@ struct RenderOutput {              // rasterizer/rasterizer.hpp:27-46
     torch::Tensor packed;
     torch::Tensor colour_gate;     // from the projection; undefined = render_backward recomputes the gate from the coefficients
     // [N, 16] accumulator of the blend backward, already cleared by the forward blend (which leaves HBM idle); handed
-    // to ONE render_backward, which takes it out of the struct (hence mutable)
+    // to ONE render_backward, which takes it out of the struct (hence mutable).  COPIES of a RenderOutput share the
+    // buffer; `accum_used` (shared by the copies) makes "one" hold across them: the second backward - through whichever
+    // copy - finds the flag set and fills a fresh accumulator instead of adding onto the first one's rows.
     mutable torch::Tensor zeroed_accum;
+    std::shared_ptr<std::atomic<bool>> accum_used;
 };
 struct BackwardOutput { torch::Tensor dL_dpositions, dL_drotations, dL_dscales, dL_dopacities, dL_dsh_coeffs, dL_dmeans_2d; };
 

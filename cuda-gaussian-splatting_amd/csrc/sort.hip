@@ -1043,10 +1043,11 @@ extern "C" size_t cugs_sort_pair_workspace_bytes(int64_t total_pairs) {
 // Everything that does not depend on the pair count runs BEFORE the blocking read-back, so the
 // device is busy (depth keys, the depth sort, per-block pair sums and their scan) while the
 // host waits for the 8-byte total - the reference idles on cumsum[-1].item() instead (sorting.cu:146).
-extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const float* depths,
+namespace {
+int sort_count_pairs_impl(int64_t n, const float* means_2d, const float* depths,
                                      const int32_t* radii, const int32_t* tiles_touched, int width,
                                      int height, void* workspace, size_t workspace_bytes,
-                                     int64_t* total_pairs_host, void* stream) {
+                                     int64_t* total_pairs_host, void* stream, bool wide) {
     if (n < 0 || width < 0 || height < 0 || !total_pairs_host) return CUGS_EINVAL;
     *total_pairs_host = 0;
     if (n == 0) return 0;
@@ -1057,7 +1058,9 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ntx = (width + CUGS_TILE - 1) / CUGS_TILE, nty = (height + CUGS_TILE - 1) / CUGS_TILE;
     if (ntx > 32767 || nty > 32767) return CUGS_EOVERFLOW;          // rectangle extents travel as 16-bit halves
-    int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st);
+    // wide: the caller knows this view's depths leave the range of the three-pass depth sort (an earlier sort of it
+    // said so): the general four-pass route at once instead of a wasted three-pass attempt
+    int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st, nullptr, !wide);
     if (rc) return rc;
 #ifdef CUGS_DEV
     // development build: first blocking sort of the process verifies the LDS ordering the atomic ranking relies on
@@ -1090,6 +1093,23 @@ extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const flo
         return CUGS_EOVERFLOW;
     }
     return 0;
+}
+}  // namespace
+
+extern "C" int cugs_sort_count_pairs(int64_t n, const float* means_2d, const float* depths,
+                                     const int32_t* radii, const int32_t* tiles_touched, int width,
+                                     int height, void* workspace, size_t workspace_bytes,
+                                     int64_t* total_pairs_host, void* stream) {
+    return sort_count_pairs_impl(n, means_2d, depths, radii, tiles_touched, width, height, workspace, workspace_bytes,
+                                 total_pairs_host, stream, false);
+}
+
+extern "C" int cugs_sort_count_pairs_wide(int64_t n, const float* means_2d, const float* depths,
+                                          const int32_t* radii, const int32_t* tiles_touched, int width,
+                                          int height, void* workspace, size_t workspace_bytes,
+                                          int64_t* total_pairs_host, void* stream) {
+    return sort_count_pairs_impl(n, means_2d, depths, radii, tiles_touched, width, height, workspace, workspace_bytes,
+                                 total_pairs_host, stream, true);
 }
 
 extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* means_2d,
@@ -1133,7 +1153,8 @@ int sort_pairs_predicted_impl(int64_t n, int64_t capacity, const float* means_2d
                               const int32_t* radii, const int32_t* tiles_touched, int width, int height,
                               void* workspace, size_t workspace_bytes, void* pair_workspace,
                               size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
-                              int32_t* tile_ranges, int64_t* total_pairs_host, void* stream, bool prekeyed) {
+                              int32_t* tile_ranges, int64_t* total_pairs_host, void* stream, bool prekeyed,
+                              bool wide = false) {
     if (n < 0 || capacity < 0 || width < 0 || height < 0 || !tile_ranges || !total_pairs_host) return CUGS_EINVAL;
     if (n > 2147483647ll || capacity > 2147483647ll) return CUGS_EOVERFLOW;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1159,8 +1180,8 @@ int sort_pairs_predicted_impl(int64_t n, int64_t capacity, const float* means_2d
         else
             (void)hipGetLastError();                              // an unregistered pointer is not an error here
     }
-    int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st, mapped, true,
-                         prekeyed);
+    int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st, mapped, !wide,
+                         prekeyed && !wide);
     if (rc) return rc;
     if (!mapped)
         CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -1199,6 +1220,18 @@ extern "C" int cugs_sort_pairs_predicted_keyed(int64_t n, int64_t capacity, cons
     return sort_pairs_predicted_impl(n, capacity, means_2d, depths, radii, tiles_touched, width, height, workspace,
                                      workspace_bytes, pair_workspace, pair_workspace_bytes, keys_sorted, values_sorted,
                                      tile_ranges, total_pairs_host, stream, true);
+}
+
+// cugs_sort_pairs_predicted on the GENERAL depth route (four 8-bit passes over the raw depth bits): for views whose
+// depths leave the range of the three-pass sort - an earlier sort of the view reported -1.  Never reports -1 itself.
+extern "C" int cugs_sort_pairs_predicted_wide(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
+                                              const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                                              void* workspace, size_t workspace_bytes, void* pair_workspace,
+                                              size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                                              int32_t* tile_ranges, int64_t* total_pairs_host, void* stream) {
+    return sort_pairs_predicted_impl(n, capacity, means_2d, depths, radii, tiles_touched, width, height, workspace,
+                                     workspace_bytes, pair_workspace, pair_workspace_bytes, keys_sorted, values_sorted,
+                                     tile_ranges, total_pairs_host, stream, false, true);
 }
 
 #ifdef CUGS_DEV

@@ -45,7 +45,16 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous().to(torch.float32)
 
 
+# Host-side state of the sort - scratch, pair-count prediction, held capacity, depth-route bit - is kept per
+# (device, STREAM): two renders queued on two streams of one device run concurrently and must not share a workspace
+# (cugs_project_forward_keyed writes the sort keys into it) nor steer each other's predictions.  The library itself
+# keeps no state; this is the caller-owned scratch of include/cugs_hip.h, one set per stream that renders.
 _workspaces: Dict[tuple, torch.Tensor] = {}
+
+
+def _skey(device: torch.device) -> tuple:
+    """(device, current stream of that device): the key of all per-stream host state."""
+    return (device, int(torch.cuda.current_stream(device).cuda_stream))
 
 
 _pinned = {}
@@ -82,7 +91,7 @@ def _workspace(device: torch.device, nbytes: int, kind: str = "n") -> torch.Tens
     """Caller-owned scratch for the sort: grown on demand, reused across calls (the reference
     allocates CUB temp storage on every call, sorting.cu:198-200).  `kind`: "n" = the N-level buffer
     that carries state from cugs_sort_count_pairs to cugs_sort_pairs, "p" = the pair-level buffer."""
-    key = (device, kind)
+    key = (_skey(device), kind)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
@@ -187,7 +196,10 @@ def evaluate_sh_backward_cuda(degree: int, sh_coeffs: torch.Tensor, directions: 
 
 
 def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Tensor,
-                   tiles_touched: torch.Tensor, img_w: int, img_h: int, want_keys: bool = True) -> SortingOutput:
+                   tiles_touched: torch.Tensor, img_w: int, img_h: int, want_keys: bool = True,
+                   wide_depth: bool = False) -> SortingOutput:
+    """`wide_depth` (not in the reference): the caller knows that this view's depths leave the range of the three-pass
+    depth ordering (an earlier sort reported -1): the general route at once (cugs_sort_count_pairs_wide)."""
     _torch_check(means_2d.is_cuda, "means_2d must be on CUDA")
     n = int(means_2d.shape[0])
     dev = means_2d.device
@@ -204,9 +216,9 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
     means_c, depths_c, radii_c = means_2d.contiguous(), depths.contiguous(), radii.contiguous()
     ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n")
     if n > 0:
-        check(lib.cugs_sort_count_pairs(n, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w),
-                                        int(img_h), _ptr(ws), ws.numel(),
-                                        C.cast(total.data_ptr(), C.POINTER(C.c_int64)), st), "cugs_sort_count_pairs")
+        count = lib.cugs_sort_count_pairs_wide if wide_depth else lib.cugs_sort_count_pairs
+        check(count(n, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w), int(img_h), _ptr(ws),
+                    ws.numel(), C.cast(total.data_ptr(), C.POINTER(C.c_int64)), st), "cugs_sort_count_pairs")
     p = int(total[0])
     slot.release()
     keys = torch.empty((p if want_keys else 0,), dtype=torch.int64, device=dev)
@@ -235,15 +247,23 @@ PREDICT_MARGIN = (1.10, 65536)      # capacity = estimate * 1.10 + 64 Ki
 # caching allocator answers a stream of slightly different sizes with splits and, now and then, a hipMalloc (a device
 # synchronisation: ~1 ms per step at 6 M Gaussians while Adam moves the scene).
 _held_capacity = {}
+# (device, stream) -> sorts left on the GENERAL depth route.  A sort that reports -1 (a splat that emits pairs lies
+# outside [0.2, ~13 107): scenes in millimetres, far backdrops) makes the bit sticky: the following sorts on that
+# stream go straight to cugs_sort_pairs_predicted_wide / cugs_sort_count_pairs_wide instead of paying a wasted
+# three-pass attempt, a wasted blend and a blocking re-sort on every frame; after WIDE_DEPTH_HOLD sorts the narrow
+# route is probed again (one wasted attempt if the view is still wide).
+_wide_depth = {}
+WIDE_DEPTH_HOLD = 256
 
 
 def _capacity_for(dev, estimate: int) -> int:
     needed = min(int(estimate * PREDICT_MARGIN[0]) + PREDICT_MARGIN[1], 2147483647)
-    held = _held_capacity.get(dev)
+    key = _skey(dev)
+    held = _held_capacity.get(key)
     if held is not None and needed <= held <= needed * 1.25:
         return held
     cap = needed if held is None or needed < held else min(int(needed * 1.05), 2147483647)
-    _held_capacity[dev] = cap
+    _held_capacity[key] = cap
     return cap
 
 
@@ -253,25 +273,34 @@ class PendingSort:
     valid the prediction was too small and everything launched on these buffers must be redone with the
     returned (exact) SortingOutput."""
 
-    def __init__(self, args, keys, vals, tile_ranges, capacity, slot, event):
+    def __init__(self, args, keys, vals, tile_ranges, capacity, slot, event, state_key):
         self._args, self._keys, self._vals, self.tile_ranges = args, keys, vals, tile_ranges
-        self.capacity, self._slot, self._event = capacity, slot, event
+        self.capacity, self._slot, self._event, self._key = capacity, slot, event, state_key
         self.gaussian_values_sorted = vals
+        self.wide_depth_found = False        # finish(): the miss was a depth outside the three-pass range
 
     def finish(self):
         self._event.synchronize()
         p = int(self._slot.tensor[0])
         self._slot.release()                 # the word is this sort's own until here (_PinnedSlot)
         means_2d, depths, radii, tiles, img_w, img_h, want_keys = self._args
-        if p == -1:      # a depth outside the range of the three-pass depth sort: the general route decides
-            return sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys), False
+        if p == -1:
+            # a depth outside the range of the three-pass depth sort: the general route, now and - sticky - for the
+            # following sorts on this stream; the exact count becomes the next prediction, so the NEXT render of such a
+            # view neither misses nor re-sorts
+            _wide_depth[self._key] = WIDE_DEPTH_HOLD
+            self.wide_depth_found = True
+            out = sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys, wide_depth=True)
+            _last_pairs[self._key] = out.total_pairs
+            return out, False
         _torch_check(0 <= p <= 2147483647, "pair count exceeds the reference's int indexing")
-        prev = _last_pairs.get(means_2d.device, 0)
-        _last_pairs[means_2d.device] = p if p > self.capacity else max(p, int(prev * 0.97))
+        prev = _last_pairs.get(self._key, 0)
+        _last_pairs[self._key] = p if p > self.capacity else max(p, int(prev * 0.97))
         if p <= self.capacity:
             keys = self._keys[:p] if want_keys else self._keys
             return SortingOutput(keys, self._vals[:p], self.tile_ranges, p), True
-        return sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys), False
+        return sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys,
+                              wide_depth=_wide_depth.get(self._key, 0) > 0), False
 
 
 def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Tensor,
@@ -282,13 +311,17 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
     `keyed_workspace`: ProjectionOutput.sort_workspace of project_gaussians(..., key_sort=True) for these very arrays
     and this image size - the sort's key kernel is skipped (cugs_sort_pairs_predicted_keyed)."""
     dev = means_2d.device
+    key = _skey(dev)
     n = int(means_2d.shape[0])
-    last = _last_pairs.get(dev)
+    last = _last_pairs.get(key)
     ntx = (img_w + K_TILE_SIZE - 1) // K_TILE_SIZE
     nty = (img_h + K_TILE_SIZE - 1) // K_TILE_SIZE
+    wide = _wide_depth.get(key, 0) > 0
+    if wide:
+        _wide_depth[key] -= 1                # when it reaches 0 the next sort probes the three-pass route again
     if last is None or n == 0 or ntx * nty == 0:
-        out = sort_gaussians(means_2d, depths, radii, tiles_touched, img_w, img_h, want_keys)
-        _last_pairs[dev] = out.total_pairs
+        out = sort_gaussians(means_2d, depths, radii, tiles_touched, img_w, img_h, want_keys, wide_depth=wide)
+        _last_pairs[key] = out.total_pairs
         return out
     cap = _capacity_for(dev, last)
     i32 = dict(dtype=torch.int32, device=dev)
@@ -302,13 +335,16 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
     slot = _pinned_total(dev)
     total = slot.tensor
     entry = lib.cugs_sort_pairs_predicted_keyed if keyed_workspace is not None else lib.cugs_sort_pairs_predicted
+    if wide:                                 # the general depth route rebuilds its keys from the arrays
+        entry = lib.cugs_sort_pairs_predicted_wide
     check(entry(n, cap, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w), int(img_h), _ptr(ws),
                 ws.numel(), _ptr(wp), wp.numel(), _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals),
                 _ptr(tile_ranges), C.cast(total.data_ptr(), C.POINTER(C.c_int64)), _stream(dev)),
           "cugs_sort_pairs_predicted")
     ev = torch.cuda.Event()
     ev.record()
-    return PendingSort((means_c, depths_c, radii_c, tiles_c, img_w, img_h, want_keys), keys, vals, tile_ranges, cap, slot, ev)
+    return PendingSort((means_c, depths_c, radii_c, tiles_c, img_w, img_h, want_keys), keys, vals, tile_ranges, cap, slot, ev,
+                       key)
 
 
 def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: torch.Tensor,
@@ -323,6 +359,8 @@ def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: tor
     final_T = torch.empty((img_h, img_w), dtype=torch.float32, device=dev)
     n_contrib = torch.empty((img_h, img_w), dtype=torch.int32, device=dev)
     if img_w == 0 or img_h == 0:
+        if zero_buf is not None:
+            zero_buf.zero_()                 # the promise holds without a blend launch too (render() relies on it)
         return ForwardOutput(color, final_T, n_contrib)
     bg = (C.c_float * 3)(*[float(b) for b in background])
     if zero_buf is not None:
@@ -539,6 +577,12 @@ def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: Ga
     render_out.wait()                                    # a deferred render: read the pair count now (may raise)
     # the accumulator render() had the forward blend clear is good for ONE backward
     zeroed, render_out.zeroed_accum = getattr(render_out, "zeroed_accum", None), None
+    # ... whichever copy of the RenderOutput asks first: the mark travels with the tensor, so a second backward through
+    # a copied RenderOutput (which still holds the now dirty rows) gets a fresh, filled accumulator instead
+    if zeroed is not None and getattr(zeroed, "_cugs_consumed", False):
+        zeroed = None
+    if zeroed is not None:
+        zeroed._cugs_consumed = True
     rb = rasterize_backward(dL_dcolor, render_out.means_2d, render_out.cov_2d_inv, render_out.rgb,
                             render_out.opacities_act, render_out.tile_ranges, render_out.gaussian_indices,
                             render_out.final_T, render_out.n_contrib, camera.width, camera.height,

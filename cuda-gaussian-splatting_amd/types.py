@@ -200,6 +200,10 @@ class RenderOutput:
             pending, self.pending = self.pending, None
             srt, valid = pending.finish()
             if not valid:
+                if getattr(pending, "wide_depth_found", False):
+                    raise PredictionMiss("render(defer_count=True): a splat's depth lies outside the range of the fast "
+                                         "depth ordering; render this view again - the sorts on this stream now take the "
+                                         "general route and the pair count is known, so the next render completes")
                 raise PredictionMiss("render(defer_count=True): the predicted pair capacity was too small; "
                                      "render this view again (the next prediction is already corrected)")
             self.gaussian_indices, self.total_pairs = srt.gaussian_values_sorted, srt.total_pairs

@@ -154,8 +154,19 @@ class StreamedViewCache:
         s = self._next
         self._next = (self._next + 1) % len(self._slot_buf)
         src = self._host[index]
+        cur = torch.cuda.current_stream(self.device)
         if self._slot_buf[s].numel() < src.numel():
+            # Growing a slot involves the caching allocator on BOTH sides.  The old buffer may still be the target of
+            # an upload that nobody has read (a prefetched view that was never asked for): the current stream - whose
+            # pool the block returns to, and which may hand it to its next tenant at once - waits for that upload first.
+            # The new block may be one whose previous tenant is still being read by kernels queued on the current
+            # stream: the copy stream waits for everything queued there so far, and the block is marked as used by
+            # the copy stream so that a later free does not recycle it under an upload in flight.
+            if self._slot_ready[s] is not None:
+                cur.wait_event(self._slot_ready[s])
             self._slot_buf[s] = torch.empty(int(src.numel()), dtype=torch.uint8, device=self.device)
+            self._slot_buf[s].record_stream(self._copy_stream)
+            self._copy_stream.wait_stream(cur)
         with torch.cuda.stream(self._copy_stream):
             if self._slot_free[s] is not None:
                 self._copy_stream.wait_event(self._slot_free[s])        # the slot's last reader has finished

@@ -153,6 +153,23 @@ int cugs_sort_pairs_predicted_keyed(int64_t n, int64_t capacity, const float* me
                                     size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
                                     int32_t* tile_ranges, int64_t* total_pairs_host, void* stream);
 
+/* The same two entry points on the GENERAL depth route (four 8-bit passes over the raw depth bits: any positive
+ * depth), for a caller that already knows the view leaves the three-pass range - an earlier sort of it reported -1.
+ * cugs_sort_count_pairs tries the three-pass route first and repeats on the general one; a host that renders such a
+ * view every frame (a scene in millimetres, a far backdrop) would pay that twice per frame, and
+ * cugs_sort_pairs_predicted would report -1 every time.  Outputs and every other rule are unchanged; the predicted
+ * variant never reports -1.  The host keeps the "this view is wide" bit (render() does: sticky per stream, re-probed
+ * every 256 sorts). */
+int cugs_sort_count_pairs_wide(int64_t n, const float* means_2d, const float* depths,
+                               const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                               void* workspace, size_t workspace_bytes, int64_t* total_pairs_host,
+                               void* stream);
+int cugs_sort_pairs_predicted_wide(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
+                                   const int32_t* radii, const int32_t* tiles_touched, int width, int height,
+                                   void* workspace, size_t workspace_bytes, void* pair_workspace,
+                                   size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
+                                   int32_t* tile_ranges, int64_t* total_pairs_host, void* stream);
+
 /* ---- a6: rasterize_forward (forward.cu:180-240, kernel :48-174) ---------------------
  * out_color [H,W,3], out_final_T [H,W], out_n_contrib [H,W] i32.  `packed` may be NULL
  * (records are then gathered from the four reference-layout arrays). */

@@ -433,6 +433,16 @@ int orc_sort(int n, const float* means_2d, const float* depths, const int32_t* r
 /* ------------------------------------------------------------------------- */
 /* exp(power) is cugs_blend_exp_q(q) (include/cugs_detmath.h): exp(-q/2), evaluated in base 2 and clamped below */
 /* at exp(-6), where opacity * it < 1/255 and the pair is skipped here as in the reference.                     */
+/* Which exponential the blend restatement uses (test infrastructure: tests/test_exp_sensitivity.py measures how far the
+ * image and the decisions move with the choice, i.e. what "parity with the reference's CUDA expf" can mean at all):
+ *   0  cugs_blend_exp_q(q)            - the contract: shared bit for bit with the HIP kernels (default)
+ *   1  cugs_expf(-0.5f * q)           - Cody-Waite form of round 1, the reference's own expression exp(power)
+ *   2  libm expf(-0.5f * q)           - a correctly-rounded-to-1-ulp host exp, the closest stand-in for CUDA's 2-ulp expf
+ * Modes 1 and 2 evaluate exp(power) for every power <= 0, without the clamp at exp(-6). */
+static int g_blend_exp_mode = 0;
+void orc_set_blend_exp_mode(int mode) { g_blend_exp_mode = mode; }
+int orc_get_blend_exp_mode(void) { return g_blend_exp_mode; }
+
 static inline int eval_alpha(float pxf, float pyf, float mx, float my, float a, float b, float c,
                              float opacity, float* dx_o, float* dy_o, float* exp_power_o,
                              float* alpha_o) {
@@ -443,7 +453,8 @@ static inline int eval_alpha(float pxf, float pyf, float mx, float my, float a, 
     float q = fmaf(dx, u, dy * v);
     float power = -0.5f * q;
     if (power > 0.0f) return 0;
-    float exp_power = cugs_blend_exp_q(q);
+    float exp_power = g_blend_exp_mode == 0 ? cugs_blend_exp_q(q)
+                      : g_blend_exp_mode == 1 ? cugs_expf(power) : expf(power);
     float alpha = opacity * exp_power;
     alpha = fminf(alpha, 0.99f);
     if (alpha < 1.0f / 255.0f) return 0;

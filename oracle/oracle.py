@@ -110,6 +110,23 @@ def sort(means_2d, depths, radii, tiles_touched, w, h):
     return dict(keys=keys, values=vals, tile_ranges=ranges, total_pairs=p)
 
 
+class blend_exp_mode:
+    """`with blend_exp_mode(1): ...` - the blend restatement with another exponential (0 contract, 1 Cody-Waite
+    cugs_expf(power), 2 libm expf(power)); restores the contract's on exit.  Sensitivity studies only."""
+
+    def __init__(self, mode: int):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.prev = int(_lib.orc_get_blend_exp_mode())
+        _lib.orc_set_blend_exp_mode(C.c_int(self.mode))
+        return self
+
+    def __exit__(self, *exc):
+        _lib.orc_set_blend_exp_mode(C.c_int(self.prev))
+        return False
+
+
 def host_threads() -> int:
     """Host threads this process may use (the GPU box gives a one-GPU job a share of its cores)."""
     try:

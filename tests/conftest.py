@@ -35,3 +35,13 @@ def dev(pkg):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _reset_depth_route():
+    """render()'s "this stream's views leave the fast depth range" bit is sticky by design (rasterizer._wide_depth);
+    a test that provokes it must not steer the sort route of the tests after it."""
+    yield
+    mod = sys.modules.get("cugs_amd")
+    if mod is not None and hasattr(mod, "rasterizer"):
+        mod.rasterizer._wide_depth.clear()

@@ -51,6 +51,12 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.cugs_project_forward_keyed(*args(0, 16, 3)[:-1], C.c_void_p(0x1000), 1 << 20, null) == 0
     assert lib.cugs_sort_pairs_predicted_keyed(-1, 0, null, null, null, null, 16, 16, null, 0, null, 0, null, null, null,
                                                None, null) == -1
+    assert lib.cugs_sort_pairs_predicted_wide(-1, 0, null, null, null, null, 16, 16, null, 0, null, 0, null, null, null,
+                                              None, null) == -1
+    total = C.c_int64(7)
+    assert lib.cugs_sort_count_pairs_wide(0, null, null, null, null, 16, 16, null, 0, C.byref(total), null) == 0
+    assert total.value == 0                                          # n == 0: nothing queued, count 0
+    assert lib.cugs_sort_count_pairs_wide(5, null, null, null, null, 16, 16, null, 0, C.byref(total), null) == -1
     assert lib.cugs_evaluate_sh(5, 1, 16, null, null, null, null) == -1
     assert lib.cugs_evaluate_sh(2, 1, 4, null, null, null, null) == -1
     assert lib.cugs_evaluate_sh(1, 0, 4, null, null, null, null) == 0

@@ -97,14 +97,14 @@ def test_sort_both_pair_routes(pkg, orc, dev, mu_s, dense):
     args = (t("means_2d"), t("depths"), t("radii"), t("tiles_touched"), w, h)
     R = pkg.rasterizer
     srt = pkg.sort_gaussians(*args)
-    R._last_pairs[torch.device(dev)] = ref["total_pairs"]
-    R._held_capacity.pop(torch.device(dev), None)
+    R._last_pairs[R._skey(torch.device(dev))] = ref["total_pairs"]
+    R._held_capacity.pop(R._skey(torch.device(dev)), None)
     try:
         pend = R.sort_gaussians_predicted(*args, want_keys=True)
         assert isinstance(pend, R.PendingSort)
         srt2, valid = pend.finish()
     finally:
-        R._last_pairs.pop(torch.device(dev), None)
+        R._last_pairs.pop(R._skey(torch.device(dev)), None)
     assert valid
     for out in (srt, srt2):
         assert out.total_pairs == ref["total_pairs"]
@@ -177,8 +177,8 @@ def test_sort_predicted_capacity_path(pkg, orc, dev):
                                        (ref["total_pairs"], (1.5, 4096), True),       # spare capacity
                                        (ref["total_pairs"] - 1, (1.0, 0), False),     # one short: must be detected
                                        (7, (1.0, 0), False)):
-            R._last_pairs[torch.device(dev)] = last
-            R._held_capacity.pop(torch.device(dev), None)            # the capacity of THIS estimate, not one held over
+            R._last_pairs[R._skey(torch.device(dev))] = last
+            R._held_capacity.pop(R._skey(torch.device(dev)), None)            # the capacity of THIS estimate, not one held over
             R.PREDICT_MARGIN = mg
             pend = R.sort_gaussians_predicted(*args, want_keys=True)
             assert isinstance(pend, R.PendingSort)
@@ -187,17 +187,17 @@ def test_sort_predicted_capacity_path(pkg, orc, dev):
             assert np.array_equal(np_(srt.gaussian_keys_sorted).view(np.uint64), ref["keys"])
             assert np.array_equal(np_(srt.gaussian_values_sorted), ref["values"])
             assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])
-            assert R._last_pairs[torch.device(dev)] >= ref["total_pairs"]          # running maximum, slow decay
+            assert R._last_pairs[R._skey(torch.device(dev))] >= ref["total_pairs"]          # running maximum, slow decay
         # nothing visible: the predicted path must leave every tile {0,0} and report zero pairs
-        R._last_pairs[torch.device(dev)] = 1000
-        R._held_capacity.pop(torch.device(dev), None)
+        R._last_pairs[R._skey(torch.device(dev))] = 1000
+        R._held_capacity.pop(R._skey(torch.device(dev)), None)
         z = torch.zeros(50, dtype=torch.int32, device=dev)
         pend = R.sort_gaussians_predicted(torch.zeros((50, 2), device=dev), torch.ones(50, device=dev), z, z, w, h)
         srt, valid = pend.finish()
         assert valid and srt.total_pairs == 0 and not bool(srt.tile_ranges.any()) and srt.gaussian_values_sorted.numel() == 0
     finally:
         R.PREDICT_MARGIN = margin
-        R._last_pairs.pop(torch.device(dev), None)
+        R._last_pairs.pop(R._skey(torch.device(dev)), None)
 
 
 def test_render_recovers_from_a_wrong_pair_prediction(pkg, orc, dev):
@@ -206,9 +206,9 @@ def test_render_recovers_from_a_wrong_pair_prediction(pkg, orc, dev):
     much smaller one through the spare capacity."""
     R = pkg.rasterizer
     small = _forward_both(pkg, orc, dev, 1500, 320, 240, 1, -4.0, (0.0, 0.0, 0.0), seed=5)
-    assert R._last_pairs[torch.device(dev)] < 60000
-    R._last_pairs[torch.device(dev)] = 100                       # force a gross under-prediction for the next frame
-    R._held_capacity.pop(torch.device(dev), None)
+    assert R._last_pairs[R._skey(torch.device(dev))] < 60000
+    R._last_pairs[R._skey(torch.device(dev))] = 100                       # force a gross under-prediction for the next frame
+    R._held_capacity.pop(R._skey(torch.device(dev)), None)
     for n, mu_s in ((40000, -3.6), (1500, -4.0)):                # far above the prediction, then far below it
         arrays, cam, model, settings, out, ref = _forward_both(pkg, orc, dev, n, 320, 240, 1, mu_s, (0.1, 0.2, 0.3), seed=n)
         assert out.total_pairs == ref["total_pairs"]
@@ -738,7 +738,7 @@ def test_predicted_capacity_is_held_while_the_pair_count_drifts(pkg, dev):
     the output buffer size - and fragment the caching allocator - on every step."""
     R = pkg.rasterizer
     d = torch.device(dev)
-    R._held_capacity.pop(d, None)
+    R._held_capacity.pop(R._skey(d), None)
     try:
         need = lambda e: int(e * R.PREDICT_MARGIN[0]) + R.PREDICT_MARGIN[1]
         c0 = R._capacity_for(d, 10_000_000)
@@ -749,7 +749,7 @@ def test_predicted_capacity_is_held_while_the_pair_count_drifts(pkg, dev):
         c2 = R._capacity_for(d, 2_000_000)                                                        # collapse: follow
         assert c2 == need(2_000_000)
     finally:
-        R._held_capacity.pop(d, None)
+        R._held_capacity.pop(R._skey(d), None)
 
 
 @pytest.mark.parametrize("mu_s", [-4.6, -3.0])
@@ -845,8 +845,8 @@ def test_deferred_pair_count_render(pkg, orc, dev):
         a, b = getattr(ref_g, k), getattr(grads, k)
         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), k
     # a prediction that is too small
-    R._last_pairs[torch.device(dev)] = 50
-    R._held_capacity.pop(torch.device(dev), None)
+    R._last_pairs[R._skey(torch.device(dev))] = 50
+    R._held_capacity.pop(R._skey(torch.device(dev)), None)
     margin = R.PREDICT_MARGIN
     R.PREDICT_MARGIN = (1.0, 0)
     try:
@@ -857,6 +857,57 @@ def test_deferred_pair_count_render(pkg, orc, dev):
         R.PREDICT_MARGIN = margin
     again = pkg.render(model, cam, settings, defer_count=True).wait()
     assert again.total_pairs == ref.total_pairs and torch.equal(again.color, ref.color)
+
+
+def test_deferred_render_of_a_view_outside_the_fast_depth_range(pkg, orc, dev):
+    """a view whose depths leave [0.2, ~13 107) made every predicted sort report -1: a wasted sort and blend
+    plus a blocking re-sort per frame, and render(defer_count=True).wait() raised PredictionMiss on EVERY call while
+    telling the caller to render again.  Now the stream remembers (rasterizer._wide_depth): the first deferred render of
+    such a view still misses - with a message that says why - and the retry completes on the general depth route with
+    the oracle's image; a training loop that follows the message converges in one retry."""
+    n, w, h, deg, scale = 20000, 640, 360, 1, 5000.0
+    arrays, cam = _scene(pkg, n, w, h, deg, seed=43, mu_s=-4.0)
+    arrays = dict(arrays)
+    arrays["positions"] = (arrays["positions"] * np.float32(scale)).astype(np.float32)
+    arrays["scales"] = (arrays["scales"] + np.float32(np.log(scale))).astype(np.float32)
+    ref = oracle_forward(orc, arrays, cam, degree=deg)
+    assert ref["depths"][ref["tiles_touched"] > 0].max() > 13107.0
+    model = pkg.scene.to_model(arrays, dev)
+    settings = pkg.RenderSettings(active_sh_degree=deg)
+    R = pkg.rasterizer
+    key = R._skey(torch.device(dev))
+    R._wide_depth.pop(key, None)
+    first = pkg.render(model, cam, settings)                      # blocking: seeds the prediction; route not yet known
+    assert first.total_pairs == ref["total_pairs"]
+    miss = pkg.render(model, cam, settings, defer_count=True)
+    with pytest.raises(pkg.PredictionMiss, match="general"):
+        miss.wait()
+    assert R._wide_depth.get(key, 0) > 0
+    renders = 0
+    while True:                                                   # what a training loop does with a PredictionMiss
+        renders += 1
+        assert renders <= 2
+        out = pkg.render(model, cam, settings, defer_count=True)
+        try:
+            out.wait()
+            break
+        except pkg.PredictionMiss:
+            continue
+    assert renders == 1
+    assert out.total_pairs == ref["total_pairs"]
+    assert np.array_equal(np_(out.gaussian_indices), ref["values"])
+    assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"])
+    assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32))
+    # the non-deferred render on the sticky route: no re-sort either (the pending sort it finishes is valid)
+    again = pkg.render(model, cam, settings)
+    assert np.array_equal(np_(again.color).view(np.uint32), ref["color"].view(np.uint32))
+    # the bit expires: after WIDE_DEPTH_HOLD sorts the narrow route is probed again
+    R._wide_depth[key] = 1
+    pkg.render(model, cam, settings)                              # last sort on the general route
+    assert R._wide_depth.get(key, 0) == 0
+    probe = pkg.render(model, cam, settings)                      # probes the three-pass route: -1 again -> sticky again
+    assert R._wide_depth.get(key, 0) == R.WIDE_DEPTH_HOLD
+    assert np.array_equal(np_(probe.color).view(np.uint32), ref["color"].view(np.uint32))
 
 
 def test_early_colour_gather_equals_compact_exchange(pkg, orc, dev):
@@ -967,16 +1018,25 @@ def test_depth_sort_routes(pkg, orc, dev, scale):
     args = (t(ref["means_2d"]), t(depths), t(ref["radii"]), t(ref["tiles_touched"]), w, h)
     R = pkg.rasterizer
     srt = pkg.sort_gaussians(*args)
-    R._last_pairs[torch.device(dev)] = srt.total_pairs
-    R._held_capacity.pop(torch.device(dev), None)
+    R._last_pairs[R._skey(torch.device(dev))] = srt.total_pairs
+    R._held_capacity.pop(R._skey(torch.device(dev)), None)
     try:
         pend = R.sort_gaussians_predicted(*args, want_keys=True)
         srt2, valid = pend.finish()
+        in_range = depths[ref["tiles_touched"] > 0]
+        narrow = bool(in_range.min() > 0.2 and in_range.max() < 13000.0)
+        assert valid == narrow
+        # a view outside the three-pass range is remembered (sticky per stream): the NEXT predicted sort takes the
+        # general route at once - valid, no -1, no blocking re-sort - and the blocking entry skips the wasted attempt
+        assert (R._wide_depth.get(R._skey(torch.device(dev)), 0) > 0) == (not narrow)
+        pend3 = R.sort_gaussians_predicted(*args, want_keys=True)
+        srt3, valid3 = pend3.finish()
+        assert valid3
+        srt4 = pkg.sort_gaussians(*args, wide_depth=True)
     finally:
-        R._last_pairs.pop(torch.device(dev), None)
-    in_range = depths[ref["tiles_touched"] > 0]
-    assert valid == bool(in_range.min() > 0.2 and in_range.max() < 13000.0)
-    for out in (srt, srt2):
+        R._last_pairs.pop(R._skey(torch.device(dev)), None)
+        R._wide_depth.pop(R._skey(torch.device(dev)), None)
+    for out in (srt, srt2, srt3, srt4):
         assert out.total_pairs == srt_ref["total_pairs"]
         assert np.array_equal(np_(out.gaussian_keys_sorted).view(np.uint64), srt_ref["keys"])
         assert np.array_equal(np_(out.gaussian_values_sorted), srt_ref["values"])
@@ -1002,8 +1062,8 @@ def test_projection_keys_the_sort(pkg, orc, dev, scale):
     plain = R.project_gaussians(*margs)
     assert plain.sort_workspace is None
     d = torch.device(dev)
-    R._last_pairs[d] = ref["total_pairs"]
-    R._held_capacity.pop(d, None)
+    R._last_pairs[R._skey(d)] = ref["total_pairs"]
+    R._held_capacity.pop(R._skey(d), None)
     try:
         keyed = R.project_gaussians(*margs, key_sort=True)
         pend = R.sort_gaussians_predicted(keyed.means_2d, keyed.depths, keyed.radii, keyed.tiles_touched, w, h,
@@ -1011,7 +1071,8 @@ def test_projection_keys_the_sort(pkg, orc, dev, scale):
         assert isinstance(pend, R.PendingSort)
         srt, valid = pend.finish()
     finally:
-        R._last_pairs.pop(d, None)
+        R._last_pairs.pop(R._skey(d), None)
+        R._wide_depth.pop(R._skey(d), None)
     _assert_projection_equal(keyed, ref)
     for name in ("means_2d", "depths", "cov_2d_inv", "radii", "tiles_touched", "rgb", "opacities_act", "packed", "colour_gate"):
         assert torch.equal(getattr(keyed, name), getattr(plain, name)), name

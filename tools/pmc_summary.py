@@ -33,8 +33,15 @@ for k in sorted(set(fetch) | set(write)):
     w = statistics.mean(write.get(k, [0.0])) * 1024
     out[short(k)] = {"launches_sampled": len(fetch.get(k, [])), "FETCH_SIZE_bytes_raw": round(f), "WRITE_SIZE_bytes": round(w),
                      "hbm_bytes_corrected": round(2 * f + w)}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py config3, per launch means",
+# one frame = everything between two launches of the projection: total corrected bytes of all sampled launches / frames
+frames = max((len(v) for k, v in fetch.items() if "k_project_forward" in k), default=0)
+frame_bytes = None
+if frames:
+    frame_bytes = round(sum(2 * sum(fetch.get(k, [])) * 1024 + sum(write.get(k, [])) * 1024 for k in set(fetch) | set(write)) / frames)
+json.dump({"frames_sampled": frames, "frame_hbm_bytes_corrected": frame_bytes, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py config3, per launch means",
            "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
+if frame_bytes:
+    print(f"one frame, all kernels: {frame_bytes/1e6:.1f} MB corrected over {frames} sampled frames")
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_corrected"])[:12]:
     print(f"{k:40s} fetch_raw {v['FETCH_SIZE_bytes_raw']/1e6:8.1f} MB  write {v['WRITE_SIZE_bytes']/1e6:8.1f} MB  corrected {v['hbm_bytes_corrected']/1e6:8.1f} MB")
