@@ -859,6 +859,48 @@ def test_deferred_pair_count_render(pkg, orc, dev):
     assert again.total_pairs == ref.total_pairs and torch.equal(again.color, ref.color)
 
 
+def test_two_renders_in_flight_on_two_streams(pkg, orc, dev):
+    """the host-side sort state (workspaces the projection keys, pair-count prediction, held capacity,
+    pinned count word) is per (device, STREAM).  Two different scenes are rendered on two torch streams with both
+    frames in flight at once (defer_count=True: neither call waits), several rounds; every frame must be the oracle's
+    image bit for bit and its own pair count - with one workspace per device the second projection would overwrite the
+    sort keys of the first while its sort is still running."""
+    R = pkg.rasterizer
+    scenes = []
+    for n, w, h, deg, seed, mu_s in ((40000, 640, 360, 1, 71, -4.0), (25000, 512, 384, 2, 72, -3.6)):
+        arrays, cam = _scene(pkg, n, w, h, deg, seed=seed, mu_s=mu_s)
+        ref = oracle_forward(orc, arrays, cam, degree=deg)
+        scenes.append((pkg.scene.to_model(arrays, dev), cam, pkg.RenderSettings(active_sh_degree=deg), ref))
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize(dev)
+    keys = []
+    for st, (model, cam, settings, ref) in zip(streams, scenes):          # seed each stream's prediction (blocking)
+        with torch.cuda.stream(st):
+            out = pkg.render(model, cam, settings)
+            keys.append(R._skey(torch.device(dev)))
+            assert out.total_pairs == ref["total_pairs"]
+    assert keys[0] != keys[1] and all(k in R._last_pairs for k in keys)
+    assert R._workspaces[(keys[0], "n")].data_ptr() != R._workspaces[(keys[1], "n")].data_ptr()
+    for _round in range(4):
+        outs = []
+        for st, (model, cam, settings, ref) in zip(streams, scenes):      # both queued before either is waited for
+            with torch.cuda.stream(st):
+                outs.append(pkg.render(model, cam, settings, defer_count=True))
+        for st, out, (model, cam, settings, ref) in zip(streams, outs, scenes):
+            with torch.cuda.stream(st):
+                assert out.pending is not None
+                out.wait()
+                st.synchronize()
+            assert out.total_pairs == ref["total_pairs"]
+            assert np.array_equal(np_(out.gaussian_indices), ref["values"])
+            assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"])
+            assert np.array_equal(np_(out.n_contrib), ref["n_contrib"])
+            assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32))
+    for k in keys:                                                        # leave no state behind for dead streams
+        R._last_pairs.pop(k, None); R._held_capacity.pop(k, None)
+        R._workspaces.pop((k, "n"), None); R._workspaces.pop((k, "p"), None)
+
+
 def test_deferred_render_of_a_view_outside_the_fast_depth_range(pkg, orc, dev):
     """a view whose depths leave [0.2, ~13 107) made every predicted sort report -1: a wasted sort and blend
     plus a blocking re-sort per frame, and render(defer_count=True).wait() raised PredictionMiss on EVERY call while
