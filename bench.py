@@ -107,6 +107,7 @@ def algorithmic_bytes(n, c, p, w, h):
 
 
 ADAM_LR_SCALE = 0.01  # config 4 / --adam: fraction of the reference's default learning rates (see main)
+COLOUR_OVERLAP = True  # --no-colour-overlap: the projection in one launch on the main stream (A/B)
 KEY_SORT = True      # --unkeyed-sort: the stage-by-stage route (the sort derives its keys from the projection's arrays)
 
 
@@ -123,7 +124,8 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     ev = [torch.cuda.Event(enable_timing=True) if sampled else _NoEvent() for _ in range(len(STAGES) + 1)]
     ev[0].record()
     proj = R.project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs,
-                               cam, deg, settings.scale_modifier, key_sort=KEY_SORT)
+                               cam, deg, settings.scale_modifier, key_sort=KEY_SORT,
+                               colour_on_side_stream=COLOUR_OVERLAP)   # as render(): the SH stream under the sort
     ev[1].record()
     # as in render(): the projection has keyed the sort's workspace, the sort runs on the predicted pair count, the
     # host reads the true one after queueing the blend
@@ -134,6 +136,7 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     blend = lambda s: R.rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
                                           s.gaussian_values_sorted, cam.width, cam.height, settings.background,
                                           packed=proj.packed, zero_buf=accum)
+    proj.wait_colour()                     # the blend reads rgb / the colour words of the packed records
     fwd = blend(srt)
     if isinstance(srt, R.PendingSort):
         srt, valid = srt.finish()
@@ -441,6 +444,9 @@ def main():
                          "state (reported as `spinup` in the JSON line; 0 disables)")
     ap.add_argument("--unkeyed-sort", action="store_true",
                     help="A/B: cugs_project_forward + cugs_sort_pairs_predicted instead of their _keyed variants")
+    ap.add_argument("--no-colour-overlap", action="store_true",
+                    help="A/B: the projection as ONE launch on the main stream instead of geometry + colour halves with "
+                         "the colour half on a side stream underneath the sort")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=368,
@@ -449,8 +455,9 @@ def main():
     ap.add_argument("--launcher-dry-run", action="store_true",
                     help="exercise the N-rank launch + rendezvous + one-JSON-line plumbing over gloo, no GPU work")
     args = ap.parse_args()
-    global KEY_SORT
+    global KEY_SORT, COLOUR_OVERLAP
     KEY_SORT = not args.unkeyed_sort
+    COLOUR_OVERLAP = not args.no_colour_overlap
 
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run / self_launch
     if args.gpus < 1:

@@ -57,6 +57,9 @@ SIGNATURES = {
                                   _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cugs_project_forward_keyed": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, C.POINTER(Camera), _F,
                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cugs_project_forward_geometry": (_I, [_L, _P, _P, _P, _P, C.POINTER(Camera), _F, _P, _P, _P, _P, _P, _P, _P, _P,
+                                           C.c_size_t, _P]),
+    "cugs_project_forward_colour": (_I, [_L, _I, _I, _P, _P, C.POINTER(Camera), _P, _P, _P, _P]),
     "cugs_evaluate_sh": (_I, [_I, _L, _I, _P, _P, _P, _P]),
     "cugs_evaluate_sh_backward": (_I, [_I, _L, _I, _P, _P, _P, _P, _P]),
     "cugs_pack_projected": (_I, [_L, _P, _P, _P, _P, _P, _P]),

@@ -88,12 +88,18 @@ struct ProjPtrs {
     uint32_t* sort_keys; int4* sort_rect; uint32_t* sort_range_flag;
 };
 
-template <int C, bool ALIGNED>
+// PART: 0 = the whole projection (cugs_project_forward[_keyed]); 1 = the GEOMETRY half - everything that does not need
+// the SH coefficients: 44 B/Gaussian in, the sort's inputs out (cugs_project_forward_geometry); 2 = the COLOUR half -
+// SH rows -> rgb, gate bits and the colour chunk of the packed records (cugs_project_forward_colour).  The halves call
+// the same device functions as the whole: identical bits.  render() queues the colour half on a side stream underneath
+// the sort, which only needs the geometry half's outputs.
+template <int C, bool ALIGNED, int PART>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int degree, CamArgs cam,
                                                                 ProjPtrs p) {
     constexpr int LROW = ShTile<C>::LROW;
     constexpr int OUT_F = 6 * CUGS_BLOCK + CUGS_PACKED_STRIDE * CUGS_BLOCK;      // staged outputs: rgb, cov, packed
-    __shared__ __attribute__((aligned(16))) float s_sh[CUGS_BLOCK * LROW > OUT_F ? CUGS_BLOCK * LROW : OUT_F];
+    constexpr int SH_F = (PART == 1) ? 0 : CUGS_BLOCK * LROW;                    // the geometry half stages no SH rows
+    __shared__ __attribute__((aligned(16))) float s_sh[SH_F > OUT_F ? SH_F : OUT_F];
 
     const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
     const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
@@ -103,36 +109,61 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
     const bool live = idx < n;
     const int64_t ld = live ? idx : (n - 1);
     const V3 pos{cugs_ldnt(p.positions + ld * 3 + 0), cugs_ldnt(p.positions + ld * 3 + 1), cugs_ldnt(p.positions + ld * 3 + 2)};
-    const float in_opa = cugs_ldnt(p.opacities + ld);
-    const float in_s0 = cugs_ldnt(p.scales + ld * 3 + 0), in_s1 = cugs_ldnt(p.scales + ld * 3 + 1), in_s2 = cugs_ldnt(p.scales + ld * 3 + 2);
-    const float4 q = ALIGNED ? cugs_ldnt(reinterpret_cast<const float4*>(p.rotations) + ld)
-                             : make_float4(p.rotations[ld * 4 + 0], p.rotations[ld * 4 + 1],
-                                           p.rotations[ld * 4 + 2], p.rotations[ld * 4 + 3]);
-    stage_sh_rows<C, ALIGNED>(p.sh, base, count, s_sh);
-    __syncthreads();
-    if (!live) return;
-
-    // --- colour: evaluated for every Gaussian, culled ones included ---
-    const V3 dir = view_direction(pos, cam);
-    const float* row = s_sh + threadIdx.x * LROW;
-    float col[3];
-    // (raw < 0 ? 0 : raw) rather than fmaxf: clamp_min keeps a NaN, fmaxf would drop it.
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        float raw = sh_colour(degree, row + ch * C, 1, dir);
-        col[ch] = (raw < 0.0f) ? 0.0f : raw;
+    float in_opa = 0.0f, in_s0 = 0.0f, in_s1 = 0.0f, in_s2 = 0.0f;
+    float4 q = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (PART != 2) {
+        in_opa = cugs_ldnt(p.opacities + ld);
+        in_s0 = cugs_ldnt(p.scales + ld * 3 + 0); in_s1 = cugs_ldnt(p.scales + ld * 3 + 1); in_s2 = cugs_ldnt(p.scales + ld * 3 + 2);
+        q = ALIGNED ? cugs_ldnt(reinterpret_cast<const float4*>(p.rotations) + ld)
+                    : make_float4(p.rotations[ld * 4 + 0], p.rotations[ld * 4 + 1], p.rotations[ld * 4 + 2],
+                                  p.rotations[ld * 4 + 3]);
     }
-    // the ReLU gate of the SH backward, made here while the coefficients are in LDS: bit ch = the backward's own
-    // recomputation of channel ch is > 0 (sh_backward.cu:92-99) - not `col[ch] > 0`, see raw_colour_backward
-    if (p.colour_gate) {                                               // kernel-uniform
-        float Y[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        sh_basis(degree, dir, Y);
-        const int num_active = (degree + 1) * (degree + 1);
-        unsigned bits = 0u;
+    float col[3] = {0.0f, 0.0f, 0.0f};
+    if constexpr (PART != 1) {
+        stage_sh_rows<C, ALIGNED>(p.sh, base, count, s_sh);
+        __syncthreads();
+        if (!live) return;
+
+        // --- colour: evaluated for every Gaussian, culled ones included ---
+        const V3 dir = view_direction(pos, cam);
+        const float* row = s_sh + threadIdx.x * LROW;
+        // (raw < 0 ? 0 : raw) rather than fmaxf: clamp_min keeps a NaN, fmaxf would drop it.
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-            bits |= (raw_colour_backward(row + ch * C, Y, num_active) > 0.0f) ? (1u << ch) : 0u;
-        p.colour_gate[idx] = (uint8_t)bits;
+        for (int ch = 0; ch < 3; ++ch) {
+            float raw = sh_colour(degree, row + ch * C, 1, dir);
+            col[ch] = (raw < 0.0f) ? 0.0f : raw;
+        }
+        // the ReLU gate of the SH backward, made here while the coefficients are in LDS: bit ch = the backward's own
+        // recomputation of channel ch is > 0 (sh_backward.cu:92-99) - not `col[ch] > 0`, see raw_colour_backward
+        if (p.colour_gate) {                                               // kernel-uniform
+            float Y[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            sh_basis(degree, dir, Y);
+            const int num_active = (degree + 1) * (degree + 1);
+            unsigned bits = 0u;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                bits |= (raw_colour_backward(row + ch * C, Y, num_active) > 0.0f) ? (1u << ch) : 0u;
+            p.colour_gate[idx] = (uint8_t)bits;
+        }
+    } else {
+        if (!live) return;
+    }
+    if constexpr (PART == 2) {
+        // the colour half's outputs: rgb rows (through LDS to 16-byte stores for a full aligned workgroup) and the
+        // colour chunk of this Gaussian's packed record (words 8..11: one 16-byte store)
+        if (p.packed)
+            reinterpret_cast<float4*>(p.packed + idx * CUGS_PACKED_STRIDE)[2] = make_float4(col[0], 0.0f, col[1], col[2]);
+        if (ALIGNED && count == CUGS_BLOCK) {
+            __syncthreads();                                   // every thread has read its SH row
+            const int t = threadIdx.x;
+            s_sh[t * 3 + 0] = col[0]; s_sh[t * 3 + 1] = col[1]; s_sh[t * 3 + 2] = col[2];
+            __syncthreads();
+            if (t < 3 * CUGS_BLOCK / 4)
+                reinterpret_cast<float4*>(p.rgb + base * 3)[t] = reinterpret_cast<const float4*>(s_sh)[t];
+        } else {
+            p.rgb[idx * 3 + 0] = col[0]; p.rgb[idx * 3 + 1] = col[1]; p.rgb[idx * 3 + 2] = col[2];
+        }
+        return;
     }
 
     // --- geometry ---
@@ -187,7 +218,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
         // records are transposed through LDS (the SH tile is dead by now) and leave as contiguous 16-byte
         // stores - a third of the write requests of per-thread strided stores.
         reinterpret_cast<float2*>(p.means_2d)[idx] = make_float2(mx, my);
-        __syncthreads();                                       // every thread has read its SH row
+        if constexpr (PART == 0) __syncthreads();              // every thread has read its SH row
         float* s_rgb = s_sh;
         float* s_cov = s_sh + 3 * CUGS_BLOCK;
         float4* s_pk = reinterpret_cast<float4*>(s_sh + 6 * CUGS_BLOCK);          // 1536 floats in: 16-byte aligned
@@ -200,21 +231,40 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
         s_pk[t * 3 + 2] = make_float4(col[0], 0.0f, col[1], col[2]);
         __syncthreads();
         if (t < 3 * CUGS_BLOCK / 4) {
-            reinterpret_cast<float4*>(p.rgb + base * 3)[t] = reinterpret_cast<const float4*>(s_rgb)[t];
+            if constexpr (PART == 0) reinterpret_cast<float4*>(p.rgb + base * 3)[t] = reinterpret_cast<const float4*>(s_rgb)[t];
             reinterpret_cast<float4*>(p.cov_2d_inv + base * 3)[t] = reinterpret_cast<const float4*>(s_cov)[t];
         }
         float4* g_pk = reinterpret_cast<float4*>(p.packed + base * CUGS_PACKED_STRIDE);
+        if constexpr (PART == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) g_pk[t + k * CUGS_BLOCK] = s_pk[t + k * CUGS_BLOCK];
+            for (int k = 0; k < 3; ++k) g_pk[t + k * CUGS_BLOCK] = s_pk[t + k * CUGS_BLOCK];
+        } else {
+            // geometry half: words 0..7 of every record (the colour half owns words 8..11): of the tile's 768 16-byte
+            // chunks the two of three that are geometry, still as contiguous lane-strided stores
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int e = t + k * CUGS_BLOCK;
+                if (e % 3 != 2) g_pk[e] = s_pk[e];
+            }
+        }
         return;
     }
     p.means_2d[idx * 2 + 0] = mx;
     p.means_2d[idx * 2 + 1] = my;
-    p.rgb[idx * 3 + 0] = col[0]; p.rgb[idx * 3 + 1] = col[1]; p.rgb[idx * 3 + 2] = col[2];
+    if constexpr (PART == 0) { p.rgb[idx * 3 + 0] = col[0]; p.rgb[idx * 3 + 1] = col[1]; p.rgb[idx * 3 + 2] = col[2]; }
     p.cov_2d_inv[idx * 3 + 0] = inv.a;
     p.cov_2d_inv[idx * 3 + 1] = inv.b;
     p.cov_2d_inv[idx * 3 + 2] = inv.c;
-    if (p.packed) write_packed(p.packed, idx, mx, my, inv, col[0], col[1], col[2], opa);
+    if (p.packed) {
+        if constexpr (PART == 0) {
+            write_packed(p.packed, idx, mx, my, inv, col[0], col[1], col[2], opa);
+        } else {
+            const float tau = (opa >= (1.0f / 255.0f)) ? logf(255.0f * opa) : -1.0f;   // as write_packed
+            float4* rec = reinterpret_cast<float4*>(p.packed + idx * CUGS_PACKED_STRIDE);
+            rec[0] = make_float4(mx, my, inv.a, inv.b);
+            rec[1] = make_float4(inv.c, opa, tau, 0.0f);
+        }
+    }
 }
 
 // ---- standalone SH forward (evaluate_sh_cuda, core/sh.cu:81-123): unclamped ----
@@ -264,14 +314,14 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_pack_projected(int64_t n,
 
 inline int grid_for(int64_t n) { return (int)((n + CUGS_BLOCK - 1) / CUGS_BLOCK); }
 
-template <int C>
+template <int C, int PART = 0>
 int launch_project(int64_t n, int degree, const CamArgs& cam, const ProjPtrs& p, bool aligned,
                    hipStream_t st) {
     if (aligned)
-        hipLaunchKernelGGL((k_project_forward<C, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n,
+        hipLaunchKernelGGL((k_project_forward<C, true, PART>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n,
                            degree, cam, p);
     else
-        hipLaunchKernelGGL((k_project_forward<C, false>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n,
+        hipLaunchKernelGGL((k_project_forward<C, false, PART>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n,
                            degree, cam, p);
     CUGS_LAUNCH_CHECK();
     return 0;
@@ -357,6 +407,57 @@ extern "C" int cugs_project_forward_keyed(int64_t n, int num_coeffs, int active_
     return project_forward_impl(n, num_coeffs, active_degree, positions, rotations, scales, opacities, sh_coeffs,
                                 camera_host, scale_modifier, means_2d, depths, cov_2d_inv, radii, tiles_touched,
                                 opacities_act, rgb, packed, colour_gate, sort_workspace, sort_workspace_bytes, stream);
+}
+
+// ---- the projection in two launches (render(): the colour half travels on a side stream underneath the sort) -------
+extern "C" int cugs_project_forward_geometry(int64_t n, const float* positions, const float* rotations,
+                                             const float* scales, const float* opacities,
+                                             const cugs_camera* camera_host, float scale_modifier, float* means_2d,
+                                             float* depths, float* cov_2d_inv, int32_t* radii, int32_t* tiles_touched,
+                                             float* opacities_act, float* packed, void* sort_workspace,
+                                             size_t sort_workspace_bytes, void* stream) {
+    if (n < 0 || !camera_host) return CUGS_EINVAL;
+    if (n == 0) return 0;
+    if (!positions || !rotations || !scales || !opacities || !means_2d || !depths || !cov_2d_inv || !radii ||
+        !tiles_touched || !opacities_act)
+        return CUGS_EINVAL;
+    if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
+    if (n > (int64_t)2147483647) return CUGS_EOVERFLOW;
+    const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
+    ProjPtrs p{positions, rotations, scales, opacities, nullptr, means_2d, depths, cov_2d_inv, radii, tiles_touched,
+               opacities_act, nullptr, packed, nullptr, nullptr, nullptr, nullptr};
+    if (sort_workspace) {
+        int rc = cugs_sort_key_slots(sort_workspace, sort_workspace_bytes, n, camera_host->width, camera_host->height,
+                                     &p.sort_keys, &p.sort_rect, &p.sort_range_flag);
+        if (rc) return rc;
+    }
+    const bool aligned = cugs_aligned16(rotations) && cugs_aligned16(cov_2d_inv) &&
+                         (reinterpret_cast<uintptr_t>(means_2d) & 7u) == 0;
+    return launch_project<1, 1>(n, 0, cam, p, aligned, static_cast<hipStream_t>(stream));     // C is unused by this half
+}
+
+extern "C" int cugs_project_forward_colour(int64_t n, int num_coeffs, int active_degree, const float* positions,
+                                           const float* sh_coeffs, const cugs_camera* camera_host, float* rgb,
+                                           float* packed, uint8_t* colour_gate, void* stream) {
+    if (n < 0 || !camera_host) return CUGS_EINVAL;
+    if (active_degree < 0 || active_degree > 3) return CUGS_EINVAL;
+    if ((active_degree + 1) * (active_degree + 1) > num_coeffs) return CUGS_EINVAL;
+    if (num_coeffs != 1 && num_coeffs != 4 && num_coeffs != 9 && num_coeffs != 16) return CUGS_EINVAL;
+    if (n == 0) return 0;
+    if (!positions || !sh_coeffs || !rgb) return CUGS_EINVAL;
+    if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
+    if (n > (int64_t)2147483647) return CUGS_EOVERFLOW;
+    const CamArgs cam = cugs_make_cam_args(camera_host, 1.0f);                                 // the colour needs no scale
+    ProjPtrs p{positions, nullptr, nullptr, nullptr, sh_coeffs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rgb,
+               packed, colour_gate, nullptr, nullptr, nullptr};
+    const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rgb);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (num_coeffs) {
+        case 1: return launch_project<1, 2>(n, active_degree, cam, p, aligned, st);
+        case 4: return launch_project<4, 2>(n, active_degree, cam, p, aligned, st);
+        case 9: return launch_project<9, 2>(n, active_degree, cam, p, aligned, st);
+        default: return launch_project<16, 2>(n, active_degree, cam, p, aligned, st);
+    }
 }
 
 extern "C" int cugs_evaluate_sh(int degree, int64_t n, int num_coeffs, const float* sh_coeffs,

@@ -102,11 +102,36 @@ def _workspace(device: torch.device, nbytes: int, kind: str = "n") -> torch.Tens
 # --------------------------------------------------------------------------------------
 # stage functions
 # --------------------------------------------------------------------------------------
+# (device, main stream) -> the side stream the colour half of a split projection runs on
+_side_streams = {}
+
+
+def _side_stream(device: torch.device) -> torch.cuda.Stream:
+    key = _skey(device)
+    st = _side_streams.get(key)
+    if st is None:
+        # lowest priority the device offers: when the colour half (an HBM stream over 192 B/Gaussian) and the sort's
+        # small latency-bound kernels compete for a CU, the sort - the frame's critical path - should win
+        try:
+            least, _greatest = torch.cuda.Stream.priority_range()
+        except Exception:
+            least = 0
+        st = torch.cuda.Stream(device=device, priority=least)
+        _side_streams[key] = st
+    return st
+
+
 def project_gaussians(positions: torch.Tensor, rotations: torch.Tensor, scales: torch.Tensor,
                       opacities: torch.Tensor, sh_coeffs: torch.Tensor, camera: CameraInfo,
                       active_sh_degree: int, scale_modifier: float = 1.0,
-                      want_colour_gate: bool = True, key_sort: bool = False) -> ProjectionOutput:
-    """`key_sort` (not in the reference; what render() passes): the kernel also leaves the sort's per-Gaussian depth
+                      want_colour_gate: bool = True, key_sort: bool = False,
+                      colour_on_side_stream: bool = False) -> ProjectionOutput:
+    """`colour_on_side_stream` (not in the reference; what render() passes): the projection runs as two launches -
+    cugs_project_forward_geometry on the current stream, cugs_project_forward_colour on a low-priority side stream - so
+    that the sort, which needs the geometry half only, starts ~50 us earlier and the SH stream (81 % of the projection's
+    reads) travels underneath the sort's latency-bound kernels.  ProjectionOutput.colour_ready is then the event the
+    reader of rgb / colour_gate / packed must wait for (ProjectionOutput.wait_colour()).  Bit-identical outputs.
+    `key_sort` (not in the reference; what render() passes): the kernel also leaves the sort's per-Gaussian depth
     keys and tile rectangles in this device's sort workspace (cugs_project_forward_keyed), and the returned
     ProjectionOutput carries that workspace as `.sort_workspace`; sort_gaussians_predicted(..., keyed_workspace=) then
     skips its first kernel.  The sort must be the next user of the workspace on this stream.
@@ -141,6 +166,25 @@ def project_gaussians(positions: torch.Tensor, rotations: torch.Tensor, scales: 
     cam = camera.to_abi()
     outs = (_ptr(means_2d), _ptr(depths), _ptr(cov_2d_inv), _ptr(radii), _ptr(tiles_touched), _ptr(opacities_act),
             _ptr(rgb), _ptr(packed), _ptr(colour_gate))
+    if colour_on_side_stream:
+        ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n") if key_sort else None
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        start = torch.cuda.Event()
+        start.record(main)                       # the inputs (and the recycled output blocks) are ready from here on
+        check(lib.cugs_project_forward_geometry(n, _ptr(pos_c), _ptr(rot_c), _ptr(scl_c), _ptr(opa_c), C.byref(cam),
+                                                float(scale_modifier), _ptr(means_2d), _ptr(depths), _ptr(cov_2d_inv),
+                                                _ptr(radii), _ptr(tiles_touched), _ptr(opacities_act), _ptr(packed),
+                                                _ptr(ws), ws.numel() if ws is not None else 0, _stream(dev)),
+              "cugs_project_forward_geometry")
+        side.wait_event(start)
+        check(lib.cugs_project_forward_colour(n, num_coeffs, int(active_sh_degree), _ptr(pos_c), _ptr(sh_c), C.byref(cam),
+                                              _ptr(rgb), _ptr(packed), _ptr(colour_gate),
+                                              C.c_void_p(side.cuda_stream)), "cugs_project_forward_colour")
+        done = torch.cuda.Event()
+        done.record(side)
+        return ProjectionOutput(means_2d, depths, cov_2d_inv, radii, tiles_touched, rgb, opacities_act, packed,
+                                colour_gate, sort_workspace=ws, colour_ready=done)
     if key_sort:
         ws = _workspace(dev, lib.cugs_sort_workspace_bytes(n), "n")
         check(lib.cugs_project_forward_keyed(n, num_coeffs, int(active_sh_degree), _ptr(pos_c), _ptr(rot_c),
@@ -501,6 +545,9 @@ def gated_colour_grad(grad_accum: torch.Tensor, colour_gate: torch.Tensor,
 # --------------------------------------------------------------------------------------
 # render / render_backward (rasterizer.cpp:22-186)
 # --------------------------------------------------------------------------------------
+OVERLAP_COLOUR = True      # render(): the projection's colour half on a side stream underneath the sort
+
+
 def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, for_backward: bool = True,
            defer_count: bool = False) -> RenderOutput:
     """`for_backward=False` (evaluation, viewer): skips preparing the backward's accumulator (64 B/Gaussian).
@@ -526,7 +573,8 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, f
     active_degree = min(int(settings.active_sh_degree), model.max_sh_degree())
     proj = project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs,
                              camera, active_degree, settings.scale_modifier, want_colour_gate=for_backward,
-                             key_sort=True)       # the sort below is the next user of this device's sort workspace
+                             key_sort=True,       # the sort below is the next user of this stream's sort workspace
+                             colour_on_side_stream=OVERLAP_COLOUR)   # the SH stream travels underneath the sort
     # the backward blend's accumulator, cleared in passing by the forward blend (which leaves HBM idle)
     accum = torch.empty((n, _lib.GRAD_STRIDE), **f) if for_backward else None
     blend = lambda s: rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
@@ -534,6 +582,7 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, f
                                         packed=proj.packed, zero_buf=accum)
     srt = sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, camera.width,
                                    camera.height, want_keys=False, keyed_workspace=proj.sort_workspace)
+    proj.wait_colour()                                   # the blend reads the colour half's outputs
     fwd = blend(srt)                                     # queued behind the sort; the host has not waited yet
     if defer_count and isinstance(srt, PendingSort):
         return RenderOutput(fwd.color, fwd.final_T, fwd.n_contrib, proj.means_2d, proj.depths, proj.cov_2d_inv,

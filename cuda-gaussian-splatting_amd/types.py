@@ -136,6 +136,16 @@ class ProjectionOutput:
     packed: Optional[torch.Tensor] = None      # [N,12] scratch for the blend kernels (not in the reference)
     colour_gate: Optional[torch.Tensor] = None # [N] uint8: the SH backward's ReLU gate bits (not in the reference)
     sort_workspace: Optional[torch.Tensor] = None  # project_gaussians(key_sort=True): the sort workspace it has keyed
+    # project_gaussians(colour_on_side_stream=True): rgb, colour_gate and the colour words of `packed` are being written
+    # on a side stream; whoever reads them must first make its stream wait for this event (wait_colour does)
+    colour_ready: Optional[object] = None
+
+    def wait_colour(self) -> "ProjectionOutput":
+        """Make the CURRENT stream wait for the colour half (no-op for a projection made in one launch)."""
+        if self.colour_ready is not None:
+            torch.cuda.current_stream(self.means_2d.device).wait_event(self.colour_ready)
+            self.colour_ready = None
+        return self
 
 
 @dataclass

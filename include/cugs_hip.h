@@ -95,6 +95,25 @@ int cugs_evaluate_sh_backward(int degree, int64_t n, int num_coeffs, const float
                               const float* directions, const float* dL_dcolor,
                               float* dL_dsh, void* stream);
 
+/* The projection in TWO launches, for a caller that overlaps the colour half with the sort (render() does: the sort
+ * needs depths / means / radii / tile counts only, while 81 % of the projection's reads - the SH rows - feed nothing
+ * before the forward blend).  Same device functions as cugs_project_forward: every output bit-identical.
+ *   cugs_project_forward_geometry  k_project_gaussians' half (projection.cu:55-189): 44 B/Gaussian in; means_2d, depths,
+ *                                  cov_2d_inv, radii, tiles_touched, opacities_act, words 0..7 of each packed record
+ *                                  and - when sort_workspace is given - the sort's keys, exactly as
+ *                                  cugs_project_forward_keyed leaves them.  sort_workspace may be NULL.
+ *   cugs_project_forward_colour    directions + k_evaluate_sh + clamp (projection.cu:273-284): rgb, colour_gate (may be
+ *                                  NULL) and words 8..11 of each packed record (packed may be NULL).
+ * The two may run concurrently on different streams (they write disjoint bytes); the blend kernels need both. */
+int cugs_project_forward_geometry(int64_t n, const float* positions, const float* rotations, const float* scales,
+                                  const float* opacities, const cugs_camera* camera_host, float scale_modifier,
+                                  float* means_2d, float* depths, float* cov_2d_inv, int32_t* radii,
+                                  int32_t* tiles_touched, float* opacities_act, float* packed, void* sort_workspace,
+                                  size_t sort_workspace_bytes, void* stream);
+int cugs_project_forward_colour(int64_t n, int num_coeffs, int active_degree, const float* positions,
+                                const float* sh_coeffs, const cugs_camera* camera_host, float* rgb, float* packed,
+                                uint8_t* colour_gate, void* stream);
+
 /* Fills `packed` from the reference-layout projection outputs, for callers that did not get
  * it from cugs_project_forward (e.g. tests that drive rasterize_forward directly). */
 int cugs_pack_projected(int64_t n, const float* means_2d, const float* cov_2d_inv,

@@ -195,7 +195,7 @@ def test_config4_fused_adam_training_steps_equal_the_unfused_path(pkg, dev, monk
             assert torch.equal(oa.m_[i], ob.m_[i]) and torch.equal(oa.v_[i], ob.v_[i]), (step, k)
         assert oa.step_count_ == ob.step_count_ == step
     moved = int((ma.positions != start).any(dim=1).sum())
-    assert moved > wl.n // 4                                                     # a real step: the model moved
+    assert moved > wl.n // 10                                                    # a real step: the visible part of the model moved
     assert bool(torch.isfinite(ma.positions).all()) and bool(torch.isfinite(ma.sh_coeffs).all())
     del ma, mb, oa, ob
     torch.cuda.empty_cache()

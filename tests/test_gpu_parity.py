@@ -859,6 +859,45 @@ def test_deferred_pair_count_render(pkg, orc, dev):
     assert again.total_pairs == ref.total_pairs and torch.equal(again.color, ref.color)
 
 
+@pytest.mark.parametrize("n,deg,stored", [(30000, 3, 3), (1000, 0, 0), (777, 1, 2), (5000, 2, 3)])
+def test_projection_in_two_halves_equals_the_whole(pkg, orc, dev, n, deg, stored):
+    """cugs_project_forward_geometry + cugs_project_forward_colour (render()'s route: the colour half on a side stream
+    underneath the sort) against cugs_project_forward_keyed: every output - the packed records, the gate bits and the
+    sort keys in the workspace included - bit for bit; ragged sizes (a partial last workgroup), every SH degree."""
+    w, h = 640, 360
+    arrays, cam = _scene(pkg, n, w, h, stored, seed=n, mu_s=-4.0)
+    model = pkg.scene.to_model(arrays, dev)
+    R = pkg.rasterizer
+    margs = (model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, cam, deg, 1.3)
+    whole = R.project_gaussians(*margs, key_sort=True)
+    halves = R.project_gaussians(*margs, key_sort=True, colour_on_side_stream=True)
+    assert halves.colour_ready is not None
+    halves.wait_colour()
+    assert halves.colour_ready is None
+    torch.cuda.synchronize(dev)
+    for name in ("means_2d", "depths", "cov_2d_inv", "radii", "tiles_touched", "rgb", "opacities_act", "packed",
+                 "colour_gate"):
+        a, b = getattr(whole, name), getattr(halves, name)
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), name
+    ref = oracle_forward(orc, arrays, cam, degree=deg, scale_mod=1.3)
+    _assert_projection_equal(halves, ref)
+    # and the sort that consumes the keys the geometry half left behind gives the oracle's order
+    key = R._skey(torch.device(dev))
+    R._last_pairs[key] = ref["total_pairs"]
+    R._held_capacity.pop(key, None)
+    try:
+        halves2 = R.project_gaussians(*margs, key_sort=True, colour_on_side_stream=True)
+        pend = R.sort_gaussians_predicted(halves2.means_2d, halves2.depths, halves2.radii, halves2.tiles_touched, w, h,
+                                          want_keys=True, keyed_workspace=halves2.sort_workspace)
+        srt, valid = pend.finish() if isinstance(pend, R.PendingSort) else (pend, True)
+        halves2.wait_colour()
+    finally:
+        R._last_pairs.pop(key, None)
+    assert valid and srt.total_pairs == ref["total_pairs"]
+    assert np.array_equal(np_(srt.gaussian_values_sorted), ref["values"])
+    assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])
+
+
 def test_two_renders_in_flight_on_two_streams(pkg, orc, dev):
     """the host-side sort state (workspaces the projection keys, pair-count prediction, held capacity,
     pinned count word) is per (device, STREAM).  Two different scenes are rendered on two torch streams with both
