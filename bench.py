@@ -107,7 +107,7 @@ def algorithmic_bytes(n, c, p, w, h):
 
 
 ADAM_LR_SCALE = 0.01  # config 4 / --adam: fraction of the reference's default learning rates (see main)
-COLOUR_OVERLAP = True  # --no-colour-overlap: the projection in one launch on the main stream (A/B)
+COLOUR_OVERLAP = False # --colour-overlap: geometry + colour halves, the colour half on a side stream under the sort (A/B)
 KEY_SORT = True      # --unkeyed-sort: the stage-by-stage route (the sort derives its keys from the projection's arrays)
 
 
@@ -369,6 +369,60 @@ def parity_probe(pkg, orc, dev):
     return res
 
 
+RCCL_ALGOS = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree"}
+RCCL_PROTOS = {0: "LL", 1: "LL128", 2: "Simple"}
+
+
+def exchange_payload(mode: str, n: int, c: int, world: int) -> dict:
+    """What ONE rank hands to the collectives of one step, and what a bandwidth-optimal (ring or direct) schedule moves
+    per rank for it: all-reduce of B bytes -> 2 (W-1)/W B sent and as much received; all-gather of B bytes per rank
+    -> (W-1) B received, (W-1)/W of the gathered buffer sent on a ring.  SURVEY 8e's figures at W = 8."""
+    geom, sh, colour = 44 * n, 12 * c * n, 12 * n
+    f = (world - 1) / world if world > 0 else 0.0
+    if mode == "allreduce":
+        coll = [{"op": "all_reduce", "bytes": geom + sh, "tensors": 5}]
+        sent = 2 * f * (geom + sh)
+    elif mode in ("compact", "compact-early"):
+        coll = [{"op": "all_gather", "bytes_per_rank": colour}, {"op": "all_reduce", "bytes": geom, "tensors": 1}]
+        sent = (world - 1) * colour + 2 * f * geom            # all-gather: W-1 blocks of `colour` bytes leave the rank
+    else:
+        coll, sent = [], 0.0
+    return {"mode": mode, "collectives": coll, "bytes_sent_per_rank": int(sent), "bytes_received_per_rank": int(sent)}
+
+
+def parse_rccl_log(paths) -> dict:
+    """Which algorithm / protocol RCCL picked, from NCCL_DEBUG=INFO lines (NCCL_DEBUG_SUBSYS=INIT,COLL,TUNING written to
+    NCCL_DEBUG_FILE).  The wording differs between RCCL versions; every line that names a collective together with an
+    algorithm and a protocol is taken, numeric ids mapped to names.  Returns {collective: ["Ring/Simple", ...]} plus the
+    channel count if announced; {} when nothing could be read (then only the raw tail is kept)."""
+    import re
+    choices, channels, tail = {}, None, []
+    pat = re.compile(r"(AllReduce|AllGather|ReduceScatter|Broadcast)\b.*?[Aa]lgo(?:rithm)?\s*[:=]?\s*(\w+).*?[Pp]roto(?:col)?\s*[:=]?\s*(\w+)")
+    chan = re.compile(r"(\d+)\s+coll channels|nChannels\s*[:=]?\s*(\d+)|Channel\s+(\d+)/(\d+)")
+    for path in paths:
+        try:
+            lines = open(path, errors="replace").read().splitlines()
+        except OSError:
+            continue
+        tail = lines[-5:]
+        for ln in lines:
+            m = pat.search(ln)
+            if m:
+                algo = RCCL_ALGOS.get(int(m.group(2)), m.group(2)) if m.group(2).isdigit() else m.group(2)
+                proto = RCCL_PROTOS.get(int(m.group(3)), m.group(3)) if m.group(3).isdigit() else m.group(3)
+                choices.setdefault(m.group(1), set()).add(f"{algo}/{proto}")
+            mc = chan.search(ln)
+            if mc:
+                vals = [int(v) for v in mc.groups() if v]
+                channels = max(channels or 0, max(vals))
+    out = {k: sorted(v) for k, v in choices.items()}
+    if channels:
+        out["channels"] = channels
+    if not out and tail:
+        out["unparsed_tail"] = [t[-160:] for t in tail]
+    return out
+
+
 def self_launch(n: int, argv) -> int:
     """`python bench.py --gpus N` without an external launcher: start N fresh child processes of this script, one
     rank (and one GPU, via LOCAL_RANK) each, with the torch.distributed rendezvous variables set.  The parent never
@@ -418,8 +472,13 @@ def launcher_dry_run(args, world, rank):
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": dist.get_world_size(), "max_over_ranks": float(t.item()),
-                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+        w = dist.get_world_size()
+        # the N > 1 diagnostics of the real line, with the fields a run over RCCL fills in left null
+        exch = {m: dict(exchange_payload(m, 1_000_000, 16, w), exposed_ms=None) for m in ("compact", "compact-early", "allreduce")}
+        print(json.dumps({"dry_run": True, "n_gpus": w, "max_over_ranks": float(t.item()),
+                          "steps": args.steps, "warmup": args.warmup,
+                          "exchange": {"mode": args.exchange, "compute_only_ms": None, "per_mode": exch, "rccl": None}}),
+              flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -432,6 +491,9 @@ def main():
     ap.add_argument("--config", default="config3", choices=["config2", "config3", "config4"])
     ap.add_argument("--adam", action="store_true", help="include FusedAdam.step in the step (implied by config4)")
     ap.add_argument("--mu-s", type=float, default=None, help="override the log-scale mean (dense variant: -3.5)")
+    ap.add_argument("--cluster", default=None, metavar="FRAC:AREA",
+                    help="skewed variant of the scene: FRAC of the Gaussians inside a centred window covering AREA of the "
+                         "screen (0.8:0.1 = 80 %% of the splats on 10 %% of the image); scene.make_gaussians(cluster=)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "compact", "compact-early", "allreduce"],
                     help="N>1 gradient exchange: compact = all-gather colour grads + all-reduce geometry grads "
                          "(SH grads rebuilt locally); compact-early = the same with the colour gather started before "
@@ -444,9 +506,12 @@ def main():
                          "state (reported as `spinup` in the JSON line; 0 disables)")
     ap.add_argument("--unkeyed-sort", action="store_true",
                     help="A/B: cugs_project_forward + cugs_sort_pairs_predicted instead of their _keyed variants")
-    ap.add_argument("--no-colour-overlap", action="store_true",
-                    help="A/B: the projection as ONE launch on the main stream instead of geometry + colour halves with "
-                         "the colour half on a side stream underneath the sort")
+    ap.add_argument("--colour-overlap", action="store_true",
+                    help="A/B: the projection as geometry + colour halves with the colour half on a side stream underneath "
+                         "the sort, instead of ONE launch on the main stream (measured slower in round 3: default off)")
+    ap.add_argument("--no-colour-overlap", action="store_true", help="(default; kept for the round-3 A/B scripts)")
+    ap.add_argument("--colour-grid-cap", type=int, default=0,
+                    help="development library only (CUGS_HIP_LIBRARY=.../libcugs_hip_dev.so): workgroups of the colour half")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=368,
@@ -457,7 +522,7 @@ def main():
     args = ap.parse_args()
     global KEY_SORT, COLOUR_OVERLAP
     KEY_SORT = not args.unkeyed_sort
-    COLOUR_OVERLAP = not args.no_colour_overlap
+    COLOUR_OVERLAP = args.colour_overlap and not args.no_colour_overlap
 
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run / self_launch
     if args.gpus < 1:
@@ -488,6 +553,12 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # which algorithm / protocol / channel count RCCL picks on this node's xGMI links is the first thing to know when
+        # the scaling curve disappoints: its INFO lines go to a per-rank file that rank 0 parses into the JSON line
+        rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cugs_bench_rccl_{os.getpid()}_%h_%p.log")
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()                                    # what RCCL actually sees
@@ -498,12 +569,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.colour_grid_cap:
+        import ctypes as _C
+        _C.CDLL(pkg.LIB_PATH).cugsdbg_colour_grid_cap(int(args.colour_grid_cap))     # AttributeError on the release build
     wl = pkg.scene.CONFIGS[args.config]
     if args.mu_s is not None:
         wl.mu_s = args.mu_s
     forward_only = args.config == "config2"
     use_adam = args.adam or args.config == "config4"
-    arrays = pkg.scene.make_gaussians(wl.n, wl.width, wl.height, sh_degree=wl.sh_degree, mu_s=wl.mu_s)
+    cluster = tuple(float(x) for x in args.cluster.split(":")) if args.cluster else None
+    arrays = pkg.scene.make_gaussians(wl.n, wl.width, wl.height, sh_degree=wl.sh_degree, mu_s=wl.mu_s, cluster=cluster)
     cam = pkg.scene.make_camera(wl.width, wl.height, view=rank)         # one distinct view per rank
     model = pkg.scene.to_model(arrays, dev)
     settings = pkg.RenderSettings(active_sh_degree=wl.sh_degree)
@@ -528,7 +603,8 @@ def main():
             out = pkg.render(model, cam, settings, for_backward=False)      # no accumulator to clear, no gate bits
             return out.total_pairs, out, None
         # under torch.distributed.run the exchange step always runs (also for a 1-rank rehearsal)
-        return timed_step(pkg, model, cam, settings, g, events, exchange["mode"], launched, opt, all_centres)
+        return timed_step(pkg, model, cam, settings, g, events, exchange["mode"], launched and exchange["mode"] != "none",
+                          opt, all_centres)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -560,8 +636,8 @@ def main():
         # Untimed, AFTER the spin-up (on ramping clocks the mode measured second would win) and before the warmup;
         # the modes alternate (two rounds of one untimed + eight timed steps each), each keeps its best round, and
         # every rank takes the same decision (MAX over ranks of each time).
-        modes = ("compact", "compact-early", "allreduce")
-        best = {m: float("inf") for m in modes}
+        modes = ("compact", "compact-early", "allreduce", "none")      # "none": the same step without any collective -
+        best = {m: float("inf") for m in modes}                        # the compute time the exchange is exposed on top of
         for _round in range(2):
             for mode in modes:
                 exchange["mode"] = mode
@@ -575,7 +651,8 @@ def main():
         t = torch.tensor([best[m] for m in modes], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         cal = [float(x) for x in t.tolist()]
-        exchange["mode"] = modes[min(range(len(modes)), key=lambda i: cal[i])]      # ties: the earlier mode
+        real = [i for i, m in enumerate(modes) if m != "none"]
+        exchange["mode"] = modes[min(real, key=lambda i: cal[i])]                   # ties: the earlier mode
         exchange["calibration_ms"] = {m: round(c_, 4) for m, c_ in zip(modes, cal)}
 
     for _ in range(args.warmup):
@@ -613,7 +690,7 @@ def main():
             gpu_ms = float(np.mean([ev[0].elapsed_time(ev[-1]) for ev in events]))
             dom = max(stages_ms, key=stages_ms.get)
             ach = alg[dom] / (stages_ms[dom] * 1e-3) / 1e9
-            plain = args.config == "config3" and args.mu_s is None and not use_adam
+            plain = args.config == "config3" and args.mu_s is None and not use_adam and not args.cluster
             traffic, table = pmc_traffic(STAGE_KERNEL.get(dom)) if plain else (None, None)
             roofline = {"bound": "hbm", "binding": "valu" if dom in ("raster_backward", "raster_forward") else "hbm",
                         "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
@@ -687,6 +764,7 @@ def main():
             "config": {"workload": wl.name + (" fwd only" if forward_only else " fwd+bwd") + (" +adam" if use_adam else ""),
                        "n_gaussians": wl.n, "width": wl.width, "height": wl.height, "sh_degree": wl.sh_degree,
                        "pairs": int(pairs), "mu_s": wl.mu_s, "views_per_step": n_gpus,
+                       **({"cluster": args.cluster} if args.cluster else {}),
                        **({"adam_learning_rates": f"{ADAM_LR_SCALE} x the reference's defaults (non-zero: a real update)"}
                           if use_adam else {}),
                        "parallelism": f"dp{n_gpus}-views" + (f"+rccl-{exchange['mode']}" if launched else ""),
@@ -694,6 +772,23 @@ def main():
             "roofline": roofline, "frame_roofline": frame,
             "stages_ms": {k: round(v, 4) for k, v in stages_ms.items()},
         }
+        if launched:
+            # N > 1 diagnostics: per exchange mode the bytes a rank puts on the wire and the EXPOSED exchange time
+            # (step time with that mode minus the compute-only step of the same box, both from the calibration rounds;
+            # for the mode that ran the timed region also from ms_per_step), and what RCCL chose
+            cal = exchange["calibration_ms"] or {}
+            base = cal.get("none")
+            per_mode = {}
+            for m in ("compact", "compact-early", "allreduce"):
+                e = exchange_payload(m, wl.n, c, n_gpus)
+                e["step_ms"] = cal.get(m)
+                e["exposed_ms"] = round(cal[m] - base, 4) if (m in cal and base is not None) else None
+                per_mode[m] = e
+            import glob as _glob
+            logs = _glob.glob(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cugs_bench_rccl_{os.getpid()}_*.log"))
+            out["exchange"] = {"mode": exchange["mode"], "compute_only_ms": base,
+                               "timed_region_exposed_ms": round(ms_per_step - base, 4) if base is not None else None,
+                               "per_mode": per_mode, "rccl": parse_rccl_log(logs) if logs else None}
         need_oracle = n_gpus == 1 and not (args.no_cpu_baseline and args.no_parity)
         orc = ge.load_oracle() if need_oracle else None
         if not args.no_cpu_baseline and n_gpus == 1:      # rank 0 at N=1 only

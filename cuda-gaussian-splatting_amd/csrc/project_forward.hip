@@ -89,10 +89,10 @@ struct ProjPtrs {
 };
 
 // PART: 0 = the whole projection (cugs_project_forward[_keyed]); 1 = the GEOMETRY half - everything that does not need
-// the SH coefficients: 44 B/Gaussian in, the sort's inputs out (cugs_project_forward_geometry); 2 = the COLOUR half -
-// SH rows -> rgb, gate bits and the colour chunk of the packed records (cugs_project_forward_colour).  The halves call
-// the same device functions as the whole: identical bits.  render() queues the colour half on a side stream underneath
-// the sort, which only needs the geometry half's outputs.
+// the SH coefficients: 44 B/Gaussian in, the sort's inputs out (cugs_project_forward_geometry).  The COLOUR half is
+// k_project_colour below (cugs_project_forward_colour).  The halves call the same device functions as the whole:
+// identical bits.  render() queues the colour half on a side stream underneath the sort, which only needs the
+// geometry half's outputs.
 template <int C, bool ALIGNED, int PART>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int degree, CamArgs cam,
                                                                 ProjPtrs p) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
     const V3 pos{cugs_ldnt(p.positions + ld * 3 + 0), cugs_ldnt(p.positions + ld * 3 + 1), cugs_ldnt(p.positions + ld * 3 + 2)};
     float in_opa = 0.0f, in_s0 = 0.0f, in_s1 = 0.0f, in_s2 = 0.0f;
     float4 q = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-    if constexpr (PART != 2) {
+    {
         in_opa = cugs_ldnt(p.opacities + ld);
         in_s0 = cugs_ldnt(p.scales + ld * 3 + 0); in_s1 = cugs_ldnt(p.scales + ld * 3 + 1); in_s2 = cugs_ldnt(p.scales + ld * 3 + 2);
         q = ALIGNED ? cugs_ldnt(reinterpret_cast<const float4*>(p.rotations) + ld)
@@ -147,23 +147,6 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
         }
     } else {
         if (!live) return;
-    }
-    if constexpr (PART == 2) {
-        // the colour half's outputs: rgb rows (through LDS to 16-byte stores for a full aligned workgroup) and the
-        // colour chunk of this Gaussian's packed record (words 8..11: one 16-byte store)
-        if (p.packed)
-            reinterpret_cast<float4*>(p.packed + idx * CUGS_PACKED_STRIDE)[2] = make_float4(col[0], 0.0f, col[1], col[2]);
-        if (ALIGNED && count == CUGS_BLOCK) {
-            __syncthreads();                                   // every thread has read its SH row
-            const int t = threadIdx.x;
-            s_sh[t * 3 + 0] = col[0]; s_sh[t * 3 + 1] = col[1]; s_sh[t * 3 + 2] = col[2];
-            __syncthreads();
-            if (t < 3 * CUGS_BLOCK / 4)
-                reinterpret_cast<float4*>(p.rgb + base * 3)[t] = reinterpret_cast<const float4*>(s_sh)[t];
-        } else {
-            p.rgb[idx * 3 + 0] = col[0]; p.rgb[idx * 3 + 1] = col[1]; p.rgb[idx * 3 + 2] = col[2];
-        }
-        return;
     }
 
     // --- geometry ---
@@ -265,6 +248,86 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
             rec[1] = make_float4(inv.c, opa, tau, 0.0f);
         }
     }
+}
+
+// ---- the COLOUR half of the projection (cugs_project_forward_colour): directions + SH + clamp + gate bits ----------
+// One workgroup walks tiles of 256 Gaussians, blockIdx.x, blockIdx.x + gridDim.x, ...: the grid is CAPPED
+// (colour_grid below) because this kernel is meant to run on a side stream underneath the sort - at three workgroups
+// per CU (its 50 KB SH tile) an uncapped grid takes every CU's LDS and the sort's workgroups queue behind it.
+template <int C, bool ALIGNED>
+__global__ __launch_bounds__(CUGS_BLOCK) void k_project_colour(int64_t n, int degree, CamArgs cam, ProjPtrs p) {
+    constexpr int LROW = ShTile<C>::LROW;
+    __shared__ __attribute__((aligned(16))) float s_sh[CUGS_BLOCK * LROW];
+    const int64_t ntiles = (n + CUGS_BLOCK - 1) / CUGS_BLOCK;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * CUGS_BLOCK;
+        const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
+        const int64_t idx = base + threadIdx.x;
+        const bool live = idx < n;
+        const int64_t ld = live ? idx : (n - 1);
+        const V3 pos{cugs_ldnt(p.positions + ld * 3 + 0), cugs_ldnt(p.positions + ld * 3 + 1), cugs_ldnt(p.positions + ld * 3 + 2)};
+        stage_sh_rows<C, ALIGNED>(p.sh, base, count, s_sh);
+        __syncthreads();
+        float col[3] = {0.0f, 0.0f, 0.0f};
+        if (live) {
+            // --- colour: evaluated for every Gaussian, culled ones included ---
+            const V3 dir = view_direction(pos, cam);
+            const float* row = s_sh + threadIdx.x * LROW;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float raw = sh_colour(degree, row + ch * C, 1, dir);
+                col[ch] = (raw < 0.0f) ? 0.0f : raw;                 // clamp_min keeps a NaN, fmaxf would drop it
+            }
+            if (p.colour_gate) {                                     // kernel-uniform; see k_project_forward
+                float Y[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                sh_basis(degree, dir, Y);
+                const int num_active = (degree + 1) * (degree + 1);
+                unsigned bits = 0u;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    bits |= (raw_colour_backward(row + ch * C, Y, num_active) > 0.0f) ? (1u << ch) : 0u;
+                p.colour_gate[idx] = (uint8_t)bits;
+            }
+            // words 8..11 of this Gaussian's packed record: one 16-byte store
+            if (p.packed)
+                reinterpret_cast<float4*>(p.packed + idx * CUGS_PACKED_STRIDE)[2] = make_float4(col[0], 0.0f, col[1], col[2]);
+        }
+        __syncthreads();                                             // every thread has read its SH row
+        if (ALIGNED && count == CUGS_BLOCK) {                        // rgb rows through LDS to 16-byte stores
+            const int t = threadIdx.x;
+            s_sh[t * 3 + 0] = col[0]; s_sh[t * 3 + 1] = col[1]; s_sh[t * 3 + 2] = col[2];
+            __syncthreads();
+            if (t < 3 * CUGS_BLOCK / 4)
+                reinterpret_cast<float4*>(p.rgb + base * 3)[t] = reinterpret_cast<const float4*>(s_sh)[t];
+            __syncthreads();                                         // before the next tile's rows land in s_sh
+        } else if (live) {
+            p.rgb[idx * 3 + 0] = col[0]; p.rgb[idx * 3 + 1] = col[1]; p.rgb[idx * 3 + 2] = col[2];
+        }
+    }
+}
+
+#ifdef CUGS_DEV
+int g_dev_colour_cap = 0;                                            // cugsdbg_colour_grid_cap: 0 = the default
+#endif
+// Workgroups of the colour half: one per CU (of the 256: 110 KB of every CU's LDS and three quarters of its wave slots
+// stay free for the sort's kernels it runs beside).
+inline int colour_grid(int64_t n) {
+    int cap = 256;
+#ifdef CUGS_DEV
+    if (g_dev_colour_cap > 0) cap = g_dev_colour_cap;
+#endif
+    const int64_t tiles = (n + CUGS_BLOCK - 1) / CUGS_BLOCK;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+template <int C>
+int launch_colour(int64_t n, int degree, const CamArgs& cam, const ProjPtrs& p, bool aligned, hipStream_t st) {
+    if (aligned)
+        hipLaunchKernelGGL((k_project_colour<C, true>), dim3(colour_grid(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p);
+    else
+        hipLaunchKernelGGL((k_project_colour<C, false>), dim3(colour_grid(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p);
+    CUGS_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---- standalone SH forward (evaluate_sh_cuda, core/sh.cu:81-123): unclamped ----
@@ -453,12 +516,16 @@ extern "C" int cugs_project_forward_colour(int64_t n, int num_coeffs, int active
     const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rgb);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (num_coeffs) {
-        case 1: return launch_project<1, 2>(n, active_degree, cam, p, aligned, st);
-        case 4: return launch_project<4, 2>(n, active_degree, cam, p, aligned, st);
-        case 9: return launch_project<9, 2>(n, active_degree, cam, p, aligned, st);
-        default: return launch_project<16, 2>(n, active_degree, cam, p, aligned, st);
+        case 1: return launch_colour<1>(n, active_degree, cam, p, aligned, st);
+        case 4: return launch_colour<4>(n, active_degree, cam, p, aligned, st);
+        case 9: return launch_colour<9>(n, active_degree, cam, p, aligned, st);
+        default: return launch_colour<16>(n, active_degree, cam, p, aligned, st);
     }
 }
+
+#ifdef CUGS_DEV
+extern "C" int cugsdbg_colour_grid_cap(int cap) { g_dev_colour_cap = cap; return 0; }
+#endif
 
 extern "C" int cugs_evaluate_sh(int degree, int64_t n, int num_coeffs, const float* sh_coeffs,
                                 const float* directions, float* out_rgb, void* stream) {

@@ -545,7 +545,9 @@ def gated_colour_grad(grad_accum: torch.Tensor, colour_gate: torch.Tensor,
 # --------------------------------------------------------------------------------------
 # render / render_backward (rasterizer.cpp:22-186)
 # --------------------------------------------------------------------------------------
-OVERLAP_COLOUR = True      # render(): the projection's colour half on a side stream underneath the sort
+OVERLAP_COLOUR = False     # render(): the projection's colour half on a side stream underneath the sort - measured
+                           # in round 3 (profiles/r03_b_colour_overlap_ab.log, r03_c_colour_grid_caps.log): the sort's
+                           # latency-bound kernels lose what the overlap saves, so the one-launch projection stays
 
 
 def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, for_backward: bool = True,

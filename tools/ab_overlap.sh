@@ -8,14 +8,14 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-parity"
 for i in 1 2; do
-  $B --steps 200 --warmup 20 > $O/${TAG}_overlap_$i.json 2>> $O/${TAG}_ab.err
+  $B --steps 200 --warmup 20 --colour-overlap > $O/${TAG}_overlap_$i.json 2>> $O/${TAG}_ab.err
   $B --steps 200 --warmup 20 --no-colour-overlap > $O/${TAG}_fused_$i.json 2>> $O/${TAG}_ab.err
 done
-$B --config config4 --steps 40 --warmup 5 > $O/${TAG}_overlap_c4.json 2>> $O/${TAG}_ab.err
+$B --config config4 --steps 40 --warmup 5 --colour-overlap > $O/${TAG}_overlap_c4.json 2>> $O/${TAG}_ab.err
 $B --config config4 --steps 40 --warmup 5 --no-colour-overlap > $O/${TAG}_fused_c4.json 2>> $O/${TAG}_ab.err
-$B --mu-s -3.5 --steps 100 --warmup 10 > $O/${TAG}_overlap_dense.json 2>> $O/${TAG}_ab.err
+$B --mu-s -3.5 --steps 100 --warmup 10 --colour-overlap > $O/${TAG}_overlap_dense.json 2>> $O/${TAG}_ab.err
 $B --mu-s -3.5 --steps 100 --warmup 10 --no-colour-overlap > $O/${TAG}_fused_dense.json 2>> $O/${TAG}_ab.err
-rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -- $B --steps 20 --warmup 5 > /dev/null 2> $O/${TAG}_trace.log
+rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -- $B --steps 20 --warmup 5 --colour-overlap > /dev/null 2> $O/${TAG}_trace.log
 python3 $R/tools/steady_kernel_stats.py $O/${TAG}_trace $O/${TAG}_overlap_kernel_stats.csv 20 k_project_forward > $O/${TAG}_overlap_kernel_stats.txt
 python3 - <<PY
 import json, glob, csv
