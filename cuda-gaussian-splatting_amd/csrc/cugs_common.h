@@ -76,3 +76,26 @@ __device__ __forceinline__ unsigned cugs_xcd_remap(unsigned bid, unsigned nwg) {
     unsigned base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
     return base + (bid >> 3);
 }
+
+// Tile of workgroup `bid` in the blend kernels: the XCD remap above gives each XCD a contiguous run of a LINEAR order of
+// the tiles - and that order walks the tile rows interleaved by eight (rows 0, 8, 16, ... then 1, 9, 17, ...), so an
+// XCD's run is every eighth row of the image rather than a band of nty / 8 adjacent rows.  With bands, a scene whose
+// splats cluster in one part of the screen (every real capture) loads the XCDs that own those rows and idles the others:
+// measured on the 80 %-on-10 % variant of config 3 (bench.py --cluster 0.8:0.1), forward blend 0.169 -> ms, backward
+// 0.406 -> ms, against 0.124 / 0.375 on the uniform scene.  Horizontal neighbours still run back to back on one XCD
+// (they share most of their Gaussians); vertical neighbours meet in the memory-side cache, which holds the whole 48 MB
+// record table.  A bijection on [0, ntx * nty) for every image size.
+__device__ __forceinline__ unsigned cugs_blend_tile(unsigned bid, unsigned ntx, unsigned nty) {
+    const unsigned lin = cugs_xcd_remap(bid, ntx * nty);
+    unsigned row = lin / ntx;                       // position in the interleaved row order
+    const unsigned col = lin - row * ntx;
+    // the row-th entry of (0, 8, 16, ..., 1, 9, 17, ..., 7, 15, ...) restricted to rows < nty: residue class c holds
+    // ceil((nty - c) / 8) rows
+    unsigned c = 0;
+#pragma unroll
+    for (unsigned k = 0; k < 7u; ++k) {
+        const unsigned cnt = (nty + 7u - c) >> 3;   // rows with residue c (0 when c >= nty)
+        if (row >= cnt) { row -= cnt; ++c; }
+    }
+    return (c + 8u * row) * ntx + col;
+}

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
         for (uint32_t e = lo + threadIdx.x; e < hi; e += CUGS_BLOCK) cugs_stnt(zero_buf + e, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     }
 
-    const unsigned tile = cugs_xcd_remap(blockIdx.x, (unsigned)geo.ntiles);
+    const unsigned tile = cugs_blend_tile(blockIdx.x, (unsigned)geo.ntx, (unsigned)(geo.ntiles / geo.ntx));
     const int tile_x = (int)(tile % (unsigned)geo.ntx), tile_y = (int)(tile / (unsigned)geo.ntx);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int quad_x = tile_x * CUGS_TILE + (wave & 1) * 8, quad_y = tile_y * CUGS_TILE + (wave >> 1) * 8;
