@@ -78,24 +78,39 @@ __device__ __forceinline__ unsigned cugs_xcd_remap(unsigned bid, unsigned nwg) {
 }
 
 // Tile of workgroup `bid` in the blend kernels: the XCD remap above gives each XCD a contiguous run of a LINEAR order of
-// the tiles - and that order walks the tile rows interleaved by eight (rows 0, 8, 16, ... then 1, 9, 17, ...), so an
-// XCD's run is every eighth row of the image rather than a band of nty / 8 adjacent rows.  With bands, a scene whose
-// splats cluster in one part of the screen (every real capture) loads the XCDs that own those rows and idles the others:
-// measured on the 80 %-on-10 % variant of config 3 (bench.py --cluster 0.8:0.1), forward blend 0.169 -> ms, backward
-// 0.406 -> ms, against 0.124 / 0.375 on the uniform scene.  Horizontal neighbours still run back to back on one XCD
-// (they share most of their Gaussians); vertical neighbours meet in the memory-side cache, which holds the whole 48 MB
-// record table.  A bijection on [0, ntx * nty) for every image size.
+// the tiles - and that order walks the tile rows in UNITS of CUGS_ROW_GROUP rows interleaved by eight (units 0, 8, 16, ...
+// then 1, 9, 17, ...), so an XCD's run is every eighth unit of the image rather than a band of nty / 8 adjacent rows.
+// With bands, a scene whose splats cluster in one part of the screen (every real capture) loads the XCDs that own those
+// rows and idles the others.  Same-box A/B (profiles/r03_f_row_interleave_ab.log; ms per fwd+bwd step: uniform config 3 |
+// 80 % of the splats on 10 % of the screen | 50 % on 2 %):  bands 0.892 | 0.976 | 1.115;  units of 1 row 0.900 | 0.944 |
+// 0.975;  2 rows 0.893 | 0.940 | 1.077;  4 rows 0.895 | 0.953 | 1.048.  Single rows balance best but cost the uniform
+// scene 1 % (vertical neighbours share Gaussians and no longer share an L2); pairs of rows cost it nothing.  Horizontal
+// neighbours run back to back on one XCD either way; what crosses XCDs meets in the memory-side cache, which holds the
+// whole 48 MB record table.  A bijection on [0, ntx * nty) for every image size (tests/test_tile_order.py).
+#ifndef CUGS_ROW_GROUP
+#define CUGS_ROW_GROUP 2      /* tile rows per interleave unit (0: no interleave - bands, the round-2 order) */
+#endif
 __device__ __forceinline__ unsigned cugs_blend_tile(unsigned bid, unsigned ntx, unsigned nty) {
     const unsigned lin = cugs_xcd_remap(bid, ntx * nty);
+#if CUGS_ROW_GROUP == 0
+    return lin;
+#else
+    constexpr unsigned G = CUGS_ROW_GROUP;
     unsigned row = lin / ntx;                       // position in the interleaved row order
     const unsigned col = lin - row * ntx;
-    // the row-th entry of (0, 8, 16, ..., 1, 9, 17, ..., 7, 15, ...) restricted to rows < nty: residue class c holds
-    // ceil((nty - c) / 8) rows
-    unsigned c = 0;
+    // units of G rows; the unit order is (0, 8, 16, ..., 1, 9, 17, ..., 7, 15, ...) restricted to units < nunits:
+    // residue class c holds ceil((nunits - c) / 8) units; the last unit of the image may be short
+    const unsigned nunits = (nty + G - 1u) / G;
+    unsigned c = 0, urow = row;                     // urow: row position counted in rows, consumed class by class
 #pragma unroll
     for (unsigned k = 0; k < 7u; ++k) {
-        const unsigned cnt = (nty + 7u - c) >> 3;   // rows with residue c (0 when c >= nty)
-        if (row >= cnt) { row -= cnt; ++c; }
+        const unsigned units = (nunits + 7u - c) >> 3;                          // units with residue c
+        // rows in class c: G per unit, minus what the image's last (short) unit lacks if it is in this class
+        const unsigned last_in = (units > 0u && ((nunits - 1u) & 7u) == c) ? 1u : 0u;
+        const unsigned rows_c = units * G - last_in * (nunits * G - nty);
+        if (urow >= rows_c) { urow -= rows_c; ++c; }
     }
-    return (c + 8u * row) * ntx + col;
+    const unsigned unit = c + 8u * (urow / G);
+    return (unit * G + urow % G) * ntx + col;
+#endif
 }
