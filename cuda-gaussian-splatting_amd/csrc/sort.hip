@@ -185,13 +185,7 @@ template <typename K, int NT, int CHUNK, int RDX = RADIX>
 __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, uint32_t count_or_cap,
                                                    const unsigned long long* __restrict__ dev_count, int shift,
                                                    uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
-                                                   uint32_t* __restrict__ ctl, uint32_t* __restrict__ zero = nullptr,
-                                                   uint32_t nzero = 0u) {
-    // housekeeping for a later kernel of the same stream (k_fill_blocksums<true> adds into the block sums)
-    if (zero) {
-        const uint32_t z = blockIdx.x * NT + threadIdx.x;
-        if (z < nzero) zero[z] = 0u;
-    }
+                                                   uint32_t* __restrict__ ctl) {
     const uint32_t count = live_count(count_or_cap, dev_count);
     constexpr int PER = CHUNK / NT;                           // consecutive keys per thread (order is irrelevant here)
     constexpr int NWORDS = PER * (int)sizeof(K) / 4;          // ... fetched as dwords in 16- or 8-byte loads
@@ -405,76 +399,22 @@ __global__ __launch_bounds__(COL_CHUNK) void k_col_hist(uint32_t n, const int4* 
     if (tid < RADIX) colhist[(size_t)tid * ncol + blockIdx.x] = s_col[tid];
 }
 
-// FIXUP = false: `order` is the final depth order.
-// FIXUP = true (the fast depth route): the two 9-bit passes have ordered the Gaussians by the TOP 18 of their 27 key
-// bits only (stable: ties in index order); the third pass over the low 9 bits - a histogram, a row scan and a scatter
-// launch, ~23 us of mostly kernel-boundary latency at 1 M Gaussians - is done HERE instead, in passing: Gaussians whose
-// keys agree in the top 18 bits stand in one run (27 on average at 1 M, depth spread over [2, 10)), and the stable order
-// by the low bits inside a run is each element's rank among the run's (low bits, position) pairs, counted from a window
-// of sorted keys in LDS.  The element then goes to its FINAL position (order_out, rect_sorted), and its tile count is
-// added to the block sum of the 256-block it lands in (zeroed by the second pass's histogram kernel).
-// What the window cannot decide is handed to the general route through the range flag, like a depth outside the fast
-// route's range: a run that reaches beyond FIX_HALO positions on either side (a plane of equal depths), and emitting
-// keys that share their top bits with the key-0 group (the Gaussians without pairs all carry key 0 and need no order).
-constexpr int FIX_HALO = 256;
-template <bool FIXUP>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_blocksums(uint32_t n,
                                                                const uint32_t* __restrict__ order,
                                                                const int4* __restrict__ rect,
                                                                int4* __restrict__ rect_sorted,
-                                                               uint32_t* __restrict__ blocksum,
-                                                               const uint32_t* __restrict__ skey,
-                                                               uint32_t* __restrict__ order_out,
-                                                               uint32_t* __restrict__ range_flag) {
+                                                               uint32_t* __restrict__ blocksum) {
     __shared__ uint32_t s_tmp[4];
     const uint32_t i = blockIdx.x * FILL_CHUNK + threadIdx.x;
-    if constexpr (!FIXUP) {
-        uint32_t acc = 0u;
-        if (i < n) {
-            const int4 r = rect[order[i]];             // the one gather per Gaussian
-            rect_sorted[i] = r;
-            acc = (uint32_t)r.w;
-        }
-        uint32_t total;
-        block_exclusive_scan(acc, s_tmp, &total);
-        if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
-    } else {
-        constexpr uint32_t LOW = (1u << DEPTH_BITS) - 1u;
-        __shared__ uint32_t s_key[FILL_CHUNK + 2 * FIX_HALO];
-        __shared__ uint32_t s_sum[3];                  // tile counts landing in the previous / this / the next block
-        const uint32_t c0 = blockIdx.x * FILL_CHUNK;
-        const uint32_t w0 = c0 >= (uint32_t)FIX_HALO ? c0 - FIX_HALO : 0u;
-        const uint32_t w1 = min(n, c0 + FILL_CHUNK + FIX_HALO);
-        for (uint32_t j = threadIdx.x; j < w1 - w0; j += CUGS_BLOCK) s_key[j] = skey[w0 + j];
-        if (threadIdx.x < 3) s_sum[threadIdx.x] = 0u;
-        __syncthreads();
-        if (i < n) {
-            const uint32_t idx = order[i];
-            const int4 r = rect[idx];                  // the one gather per Gaussian, in flight during the ranking
-            const uint32_t k = s_key[i - w0];
-            uint32_t pos = i;
-            if (k != 0u) {                             // key 0: no pairs (or quirk Q12): all equal, the stable order stands
-                const uint32_t hi = k >> DEPTH_BITS, lo = k & LOW;
-                uint32_t s = i, e = i + 1u;
-                while (s > w0 && (s_key[s - 1u - w0] >> DEPTH_BITS) == hi) --s;
-                while (e < w1 && (s_key[e - w0] >> DEPTH_BITS) == hi) ++e;
-                const bool open_left = (s == w0 && w0 > 0u), open_right = (e == w1 && w1 < n);
-                if (open_left || open_right || hi == 0u) atomicOr(range_flag, 2u);     // undecidable here: general route
-                uint32_t rank = 0u;
-                for (uint32_t q = s; q < e; ++q) {
-                    const uint32_t lq = s_key[q - w0] & LOW;
-                    rank += (lq < lo || (lq == lo && q < i)) ? 1u : 0u;
-                }
-                pos = s + rank;
-            }
-            order_out[pos] = idx;
-            rect_sorted[pos] = r;
-            // pos lies within FIX_HALO = FILL_CHUNK of i: the block before, this one, or the next
-            atomicAdd(&s_sum[pos / FILL_CHUNK + 1u - blockIdx.x], (uint32_t)r.w);
-        }
-        __syncthreads();
-        if (threadIdx.x < 3 && s_sum[threadIdx.x] != 0u) atomicAdd(&blocksum[blockIdx.x + threadIdx.x - 1u], s_sum[threadIdx.x]);
+    uint32_t acc = 0u;
+    if (i < n) {
+        const int4 r = rect[order[i]];             // the one gather per Gaussian
+        rect_sorted[i] = r;
+        acc = (uint32_t)r.w;
     }
+    uint32_t total;
+    block_exclusive_scan(acc, s_tmp, &total);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
 }
 
 // Single workgroup: exclusive scan of blocksum[0..nb) in place; *total = the 64-bit grand total =
@@ -913,13 +853,11 @@ constexpr int rank_mode() { return 0; }            // ballot ranking: defined by
 
 template <typename K, bool IOTA, int NT, int CHUNK, int RDX = RADIX>
 int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned long long* dev_count, int shift, int bits,
-               uint32_t* hist, uint32_t* tot, K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st,
-               uint32_t* zero = nullptr, uint32_t nzero = 0u) {
+               uint32_t* hist, uint32_t* tot, K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st) {
     const uint32_t nblk = nblocks_for(count, CHUNK);
-    if (zero && (hist_done || (uint64_t)nblk * NT < nzero)) return CUGS_EINVAL;     // the histogram grid does the zeroing
     if (!hist_done) {
         hipLaunchKernelGGL((k_radix_hist<K, NT, CHUNK, RDX>), dim3(nblk), dim3(NT), 0, st, kin, count, dev_count, shift,
-                           (1u << bits) - 1u, hist, nblk, ctl, zero, nzero);
+                           (1u << bits) - 1u, hist, nblk, ctl);
         CUGS_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_radix_scan_rows, dim3(RDX), dim3(CUGS_BLOCK), 0, st, hist, hist, nblk, tot);
@@ -1047,12 +985,9 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
                                means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[0], ws.rect[0], range_flag);
             CUGS_LAUNCH_CHECK();
         }
-        // two LSD passes over key bits [9, 18) and [18, 27): [0] -> [1] -> [0]; the low 9 bits are ordered by
-        // k_fill_blocksums<true> below, in passing (one histogram + row scan + scatter less: ~23 us at 1 M Gaussians).
-        // The second pass's histogram grid also zeroes the block sums the fix-up adds into.
-        const uint32_t nfill2 = nblocks_for(un, FILL_CHUNK);
-        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st, ws.blocksum, nfill2 + 2u))) return rc;
+        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
     } else {
         // (1) the general route: four passes of 8 bits on the raw depth bits (positive floats order as unsigned ints)
         hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
@@ -1066,13 +1001,8 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
     }
     // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
-    if (three_pass)      // sorted by the top 18 key bits in [0]: the fix-up leaves the final order in dval[1] / rect[1]
-        hipLaunchKernelGGL(k_fill_blocksums<true>, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[0], ws.rect[0], ws.rect[1],
-                           ws.blocksum, ws.dkey[0], ws.dval[1], range_flag);
-    else
-        hipLaunchKernelGGL(k_fill_blocksums<false>, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
-                           ws.blocksum, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
-                           static_cast<uint32_t*>(nullptr));
+    hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
+                       ws.blocksum);
     CUGS_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_NT), 0, st, ws.blocksum, nfill, ws.total,
                        reinterpret_cast<uint32_t*>(ws.total) + 4, total_mapped, three_pass ? range_flag : static_cast<uint32_t*>(nullptr));
