@@ -52,7 +52,9 @@ namespace {
 // Against reducing nine values over 64 lanes in every step (38 units) this costs ~19 units per step; the pending
 // Gaussians are flushed before the record batch they point into is re-staged.
 #define CUGS_BWD_HITS 4
-#define CUGS_BWD_HSTRIDE 66        /* float2 per Gaussian block: 64 pixels + 16 bytes (bank spread of the b128 reads) */
+#ifndef CUGS_BWD_HSTRIDE
+#define CUGS_BWD_HSTRIDE 64        /* float2 per Gaussian block: the 64 pixels, no padding - see the LDS budget below */
+#endif
 
 // WIDE: accumulator larger than 4 GiB (n > 2^26 rows): 64-bit scatter addresses.
 // STATS (dev builds only): step counters written to accumulator row `stats_row` (tools/ablate_backward.py).
@@ -62,10 +64,13 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                                                                 const float* __restrict__ final_T,
                                                                 const int32_t* __restrict__ n_contrib,
                                                                 float* __restrict__ grad_accum, int64_t stats_row) {
+    // LDS budget: 12288 B of records + 8192 B of contributions = 20480 B = 1/8 of a CU's 160 KB, so EIGHT workgroups
+    // (32 waves, the CU's limit) are resident instead of the seven that 20.8 KB allowed (round 2: 16 bytes of padding
+    // per contribution block, 64 + 16 bytes of hit-record and vote words).  The record index of each pending Gaussian
+    // travels in a wave-uniform 64-bit scalar (16 bits each), and a wave's "all my pixels are done" vote sits in the
+    // first word of its own - at that point idle - contribution block (see the loop head).
     __shared__ float4 s_rec[CUGS_BLOCK * CUGS_REC_F4];
     __shared__ float2 s_contrib[4][CUGS_BWD_HITS][CUGS_BWD_HSTRIDE];
-    __shared__ int s_hitrec[4][CUGS_BWD_HITS];
-    __shared__ int s_wave_done[4];
 
     const unsigned tile = cugs_blend_tile(blockIdx.x, (unsigned)geo.ntx, (unsigned)(geo.ntiles / geo.ntx));
     const int tile_x = (int)(tile % (unsigned)geo.ntx), tile_y = (int)(tile / (unsigned)geo.ntx);
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     }
     const int slot2 = reduce9r16_slot(lane);
     const unsigned slot_off = (unsigned)(slot2 < 0 ? 0 : slot2) * 4u;
-    if (lane < CUGS_BWD_HITS) s_hitrec[wave][lane] = 0;       // stale slots of a partial flush must stay valid indices
+    unsigned long long hitrecs = 0ull;                       // record (float4) index of pending Gaussian h in bits [16h, 16h+16);
+                                                             // stale slots of a partial flush stay valid indices
 
     // D = sum_c dL/dC_c * (colour accumulated behind the current Gaussian), starting from the background
     float D = fmaf(dC2, T * geo.bg2, fmaf(dC1, T * geo.bg1, dC0 * (T * geo.bg0)));      // backward.cu:83-87
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
 
     // phase 2 for the `cnt` pending Gaussians of this wave
     auto flush = [&](int cnt) {
-        const int rec = s_hitrec[wave][h2];                                            // float4 index of the record
+        const int rec = (int)((hitrecs >> (16 * h2)) & 0xFFFFull);                     // float4 index of the record
         const float4* c4 = reinterpret_cast<const float4*>(&s_contrib[wave][h2][g2i * 4]);
         const float4 p01 = c4[0], p23 = c4[1];                                         // (weight, v3) x 4 pixels
         const float2 mean = *reinterpret_cast<const float2*>(&s_rec[rec]);
@@ -156,9 +162,12 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     };
 
     for (int batch = num_batches - 1; batch >= 0; --batch) {
-        if (lane == 0) s_wave_done[wave] = wave_done ? 1 : 0;
+        // The vote word is the first word of the wave's own contribution block: every pending Gaussian has been flushed
+        // when a wave arrives here, nobody else touches the block, all four waves read the words between this barrier
+        // and the next, and the block is written again (phase 1) only after that next barrier.
+        if (lane == 0) s_contrib[wave][0][0].x = wave_done ? 1.0f : 0.0f;
         __syncthreads();
-        if (s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) break;
+        if (s_contrib[0][0][0].x * s_contrib[1][0][0].x * s_contrib[2][0][0].x * s_contrib[3][0][0].x != 0.0f) break;
 
         stage_record<PACKED>(src, range_start + batch * CUGS_BLOCK + tid, range_end, s_rec);
         __syncthreads();
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
                         if (lm) { ++st_contrib; st_lanes += __popcll(lm); st_open += __popcll(__ballot(open != 0.0f)); }
                     }
                     s_contrib[wave][pending][lane] = make_float2(weight, gate * e.e);
-                    if (lane == 0) s_hitrec[wave][pending] = rec;
+                    hitrecs = (hitrecs & ~(0xFFFFull << (16 * pending))) | ((unsigned long long)(unsigned)rec << (16 * pending));
                     if (++pending == CUGS_BWD_HITS) {
                         flush(CUGS_BWD_HITS);
                         pending = 0;
