@@ -215,6 +215,27 @@ __device__ __forceinline__ SortRecord sort_record_of(float depth, int tiles, int
     return SortRecord{key, make_int4(x0, y0, w | (h << 16), tiles > 0 ? tiles : 0)};
 }
 
+// The tile-rectangle record of sort_record_of in 32 bits, for images of up to 127 x 127 tiles (2032 px a side) whose tile
+// counts are the rectangles' own (the projection's; sort_gaussians takes tiles_touched as an INPUT and cannot assume it):
+//   emits pairs:       x0 | y0 << 7 | w << 14 | h << 21      (tiles = w * h)
+//   quirk Q12 / none:  1 << 31 | tiles                       (w = h = 0; tiles = 0: no pairs at all)
+// Such a record rides through the depth sort's passes beside the Gaussian index (4 more bytes per pass and Gaussian),
+// and the depth-ordered rectangles are then READ IN ORDER instead of gathered: the gather of one 16-byte record per
+// Gaussian into depth order was 19 us of the 1 M-Gaussian frame and 127 us of the 6 M one (a random 16-byte gather
+// costs a 64-byte fetch and a memory-system request each).
+constexpr int CUGS_PRECT_MAX_TILES = 127;
+__host__ __device__ inline bool cugs_prect_packable(int ntx, int nty) { return ntx <= CUGS_PRECT_MAX_TILES && nty <= CUGS_PRECT_MAX_TILES; }
+__device__ __forceinline__ uint32_t pack_rect(int4 r) {
+    const int w = r.z & 0xFFFF, h = r.z >> 16;
+    if (w == 0) return 0x80000000u | (uint32_t)r.w;
+    return (uint32_t)r.x | ((uint32_t)r.y << 7) | ((uint32_t)w << 14) | ((uint32_t)h << 21);
+}
+__device__ __forceinline__ int4 unpack_rect(uint32_t v) {
+    if (v & 0x80000000u) return make_int4(0, 0, 0, (int)(v & 0x7FFFFFFFu));
+    const int x0 = (int)(v & 127u), y0 = (int)((v >> 7) & 127u), w = (int)((v >> 14) & 127u), h = (int)((v >> 21) & 127u);
+    return make_int4(x0, y0, w | (h << 16), w * h);
+}
+
 // normalize(p - c) with the norm clamped at 1e-8 (projection.cu:278-280)
 __device__ __forceinline__ V3 view_direction(V3 p, const CamArgs& c) {
     float dx = p.x - c.cc[0], dy = p.y - c.cc[1], dz = p.z - c.cc[2];

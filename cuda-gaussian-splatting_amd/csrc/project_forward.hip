@@ -85,7 +85,7 @@ struct ProjPtrs {
     float* means_2d; float* depths; float* cov_2d_inv; int32_t* radii; int32_t* tiles_touched;
     float* opacities_act; float* rgb; float* packed; uint8_t* colour_gate;
     // cugs_project_forward_keyed: the sort's depth keys / tile rectangles / range flag (its N-level workspace), or null
-    uint32_t* sort_keys; int4* sort_rect; uint32_t* sort_range_flag;
+    uint32_t* sort_keys; int4* sort_rect; uint32_t* sort_prect; uint32_t* sort_range_flag;
 };
 
 // PART: 0 = the whole projection (cugs_project_forward[_keyed]); 1 = the GEOMETRY half - everything that does not need
@@ -194,7 +194,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
         const SortRecord rec = sort_record_of(depth, tiles, radius, tr, true, &bad);
         if (bad) atomicOr(p.sort_range_flag, 1u);
         p.sort_keys[idx] = rec.key;
-        p.sort_rect[idx] = rec.rect;
+        if (p.sort_prect) p.sort_prect[idx] = pack_rect(rec.rect);   // kernel-uniform: images of up to 127 x 127 tiles
+        else p.sort_rect[idx] = rec.rect;
     }
     if (ALIGNED && count == CUGS_BLOCK && p.packed) {
         // Full workgroup, 16-byte aligned outputs: the 12-byte-strided rgb / cov rows and the 48-byte packed
@@ -427,10 +428,10 @@ int project_forward_impl(int64_t n, int num_coeffs, int active_degree,
 
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
     ProjPtrs p{positions, rotations, scales, opacities, sh_coeffs, means_2d, depths, cov_2d_inv,
-               radii, tiles_touched, opacities_act, rgb, packed, colour_gate, nullptr, nullptr, nullptr};
+               radii, tiles_touched, opacities_act, rgb, packed, colour_gate, nullptr, nullptr, nullptr, nullptr};
     if (sort_workspace) {
         int rc = cugs_sort_key_slots(sort_workspace, sort_workspace_bytes, n, camera_host->width, camera_host->height,
-                                     &p.sort_keys, &p.sort_rect, &p.sort_range_flag);
+                                     &p.sort_keys, &p.sort_rect, &p.sort_prect, &p.sort_range_flag);
         if (rc) return rc;
     }
     const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rotations) && cugs_aligned16(rgb) &&
@@ -488,10 +489,10 @@ extern "C" int cugs_project_forward_geometry(int64_t n, const float* positions, 
     if (n > (int64_t)2147483647) return CUGS_EOVERFLOW;
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
     ProjPtrs p{positions, rotations, scales, opacities, nullptr, means_2d, depths, cov_2d_inv, radii, tiles_touched,
-               opacities_act, nullptr, packed, nullptr, nullptr, nullptr, nullptr};
+               opacities_act, nullptr, packed, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (sort_workspace) {
         int rc = cugs_sort_key_slots(sort_workspace, sort_workspace_bytes, n, camera_host->width, camera_host->height,
-                                     &p.sort_keys, &p.sort_rect, &p.sort_range_flag);
+                                     &p.sort_keys, &p.sort_rect, &p.sort_prect, &p.sort_range_flag);
         if (rc) return rc;
     }
     const bool aligned = cugs_aligned16(rotations) && cugs_aligned16(cov_2d_inv) &&
@@ -512,7 +513,7 @@ extern "C" int cugs_project_forward_colour(int64_t n, int num_coeffs, int active
     if (n > (int64_t)2147483647) return CUGS_EOVERFLOW;
     const CamArgs cam = cugs_make_cam_args(camera_host, 1.0f);                                 // the colour needs no scale
     ProjPtrs p{positions, nullptr, nullptr, nullptr, sh_coeffs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rgb,
-               packed, colour_gate, nullptr, nullptr, nullptr};
+               packed, colour_gate, nullptr, nullptr, nullptr, nullptr};
     const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rgb);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (num_coeffs) {

@@ -59,6 +59,7 @@ struct SortWsN {
     uint32_t* dkey[2];           // depth bits, ping-pong              [n]
     uint32_t* dval[2];           // Gaussian index, ping-pong          [n]
     int4* rect[2];               // {x0, y0, w | h << 16, tiles_touched} per Gaussian: [0] input order, [1] depth order
+    uint32_t* prect[2];          // the same record packed into a dword (pack_rect), riding through the depth passes  [n]
     uint32_t* tot;               // [RADIX_DEPTH]
     uint32_t* blocksum;          // per FILL_CHUNK block pair counts   [nfill + 2]
     uint32_t* hist;              // [RADIX_DEPTH][nblk_n] digit-major
@@ -89,6 +90,7 @@ SortWsN carve_n(void* base, int64_t n) {
     for (int i = 0; i < 2; ++i) w.dkey[i] = c.take<uint32_t>((size_t)n);
     for (int i = 0; i < 2; ++i) w.dval[i] = c.take<uint32_t>((size_t)n);
     for (int i = 0; i < 2; ++i) w.rect[i] = c.take<int4>((size_t)n);
+    for (int i = 0; i < 2; ++i) w.prect[i] = c.take<uint32_t>((size_t)n);
     w.tot = c.take<uint32_t>(RADIX_DEPTH);
     w.blocksum = c.take<uint32_t>((size_t)nblocks_for(n, FILL_CHUNK) + 2);
     w.hist = c.take<uint32_t>((size_t)RADIX_DEPTH * (nblocks_for(n, CHUNK_MIN) + 1));
@@ -265,11 +267,13 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_radix_scan_rows(const uint32_t* 
 // array.  NB: digit width (the match-any needs one ballot per digit bit).  NT: threads per workgroup -
 // 256 for the pair-level passes (thousands of workgroups), 1024 for the depth sort, whose 4096-item
 // chunks are too few to fill the chip with 4 waves each.
-template <typename K, bool IOTA, int NB, int NT, bool ARANK, int CHUNK, int RDX = RADIX>
+// V2: a second dword per item travels with the first (the depth sort's packed tile rectangle, pack_rect).
+template <typename K, bool IOTA, int NB, int NT, bool ARANK, int CHUNK, int RDX = RADIX, bool V2 = false>
 __global__ __launch_bounds__(NT) void k_radix_scatter(
     const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count_or_cap,
     const unsigned long long* __restrict__ dev_count, int shift, uint32_t mask_rt, const uint32_t* __restrict__ hist,
-    const uint32_t* __restrict__ tot, uint32_t nblk, K* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    const uint32_t* __restrict__ tot, uint32_t nblk, K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+    const uint32_t* __restrict__ vals2_in = nullptr, uint32_t* __restrict__ vals2_out = nullptr) {
     const uint32_t mask = ARANK ? mask_rt : ((1u << NB) - 1u);       // the ballot ranking needs the width at compile time
     const uint32_t count = live_count(count_or_cap, dev_count);
     if (blockIdx.x * CHUNK >= count) return;              // chunks beyond the live items (capacity path): nothing to move
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
     __shared__ uint32_t s_gbase[RDX];          // first global position of this workgroup's digit-d run
     __shared__ K s_key[CHUNK];
     __shared__ uint32_t s_val[CHUNK];
+    __shared__ uint32_t s_val2[V2 ? CHUNK : 1];
     __shared__ uint32_t s_tmp[NW];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t bbase = blockIdx.x * CHUNK;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
     for (uint32_t e = tid; e < NW * RDX; e += NT) (&s_lbase[0][0])[e] = 0;
     __syncthreads();
 
-    uint32_t k[PER], v[PER];
+    uint32_t k[PER], v[PER], v2[V2 ? PER : 1];
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
         uint32_t i = wbase + r * CUGS_WAVE + lane;
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
         // last use of this pass's input: streamed, so that it does not evict the output being written for the next pass
         k[r] = ok ? (uint32_t)__builtin_nontemporal_load(keys_in + i) : 0xFFFFFFFFu;
         v[r] = ok ? (IOTA ? i : __builtin_nontemporal_load(vals_in + i)) : 0u;
+        if constexpr (V2) v2[r] = ok ? __builtin_nontemporal_load(vals2_in + i) : 0u;
         if (ok) atomicAdd(&s_lbase[wave][(k[r] >> shift) & mask], 1u);
     }
     __syncthreads();
@@ -341,6 +347,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
                 const uint32_t pos = atomicAdd(&s_lbase[wave][d], 1u);
                 s_key[pos] = (K)k[r];
                 s_val[pos] = v[r];
+                if constexpr (V2) s_val2[pos] = v2[r];
             }
             continue;
         }
@@ -356,6 +363,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
             const uint32_t pos = base + __popcll(peers & lt_mask);
             s_key[pos] = (K)k[r];
             s_val[pos] = v[r];
+            if constexpr (V2) s_val2[pos] = v2[r];
             if ((peers >> lane) == 1ull) s_lbase[wave][d] = base + __popcll(peers);
         }
     }
@@ -370,6 +378,7 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
             const uint32_t dst = s_gbase[d] + (j - s_lstart[d]);
             keys_out[dst] = key;
             vals_out[dst] = s_val[j];
+            if constexpr (V2) vals2_out[dst] = s_val2[j];
         }
     }
 }
@@ -399,16 +408,20 @@ __global__ __launch_bounds__(COL_CHUNK) void k_col_hist(uint32_t n, const int4* 
     if (tid < RADIX) colhist[(size_t)tid * ncol + blockIdx.x] = s_col[tid];
 }
 
+// prect_sorted (when given): the packed rectangles arrive IN depth order (they rode through the passes): a sequential
+// read instead of the gather.
 __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_blocksums(uint32_t n,
                                                                const uint32_t* __restrict__ order,
                                                                const int4* __restrict__ rect,
                                                                int4* __restrict__ rect_sorted,
-                                                               uint32_t* __restrict__ blocksum) {
+                                                               uint32_t* __restrict__ blocksum,
+                                                               const uint32_t* __restrict__ prect_sorted) {
     __shared__ uint32_t s_tmp[4];
     const uint32_t i = blockIdx.x * FILL_CHUNK + threadIdx.x;
     uint32_t acc = 0u;
     if (i < n) {
-        const int4 r = rect[order[i]];             // the one gather per Gaussian
+        const int4 r = prect_sorted ? unpack_rect(__builtin_nontemporal_load(prect_sorted + i))
+                                    : rect[order[i]];             // the one gather per Gaussian
         rect_sorted[i] = r;
         acc = (uint32_t)r.w;
     }
@@ -853,7 +866,8 @@ constexpr int rank_mode() { return 0; }            // ballot ranking: defined by
 
 template <typename K, bool IOTA, int NT, int CHUNK, int RDX = RADIX>
 int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned long long* dev_count, int shift, int bits,
-               uint32_t* hist, uint32_t* tot, K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st) {
+               uint32_t* hist, uint32_t* tot, K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st,
+               const uint32_t* v2in = nullptr, uint32_t* v2out = nullptr) {
     const uint32_t nblk = nblocks_for(count, CHUNK);
     if (!hist_done) {
         hipLaunchKernelGGL((k_radix_hist<K, NT, CHUNK, RDX>), dim3(nblk), dim3(NT), 0, st, kin, count, dev_count, shift,
@@ -863,11 +877,16 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
     hipLaunchKernelGGL(k_radix_scan_rows, dim3(RDX), dim3(CUGS_BLOCK), 0, st, hist, hist, nblk, tot);
     CUGS_LAUNCH_CHECK();
     if constexpr (RDX == RADIX_DEPTH) {                    // the 9-bit passes of the depth sort: ballot ranking only
-        hipLaunchKernelGGL((k_radix_scatter<K, IOTA, DEPTH_BITS, NT, false, CHUNK, RDX>), dim3(nblk), dim3(NT), 0, st, kin, vin, count,
-                           dev_count, shift, 0u, hist, tot, nblk, kout, vout);
+        if (v2in)                                          // the packed tile rectangle rides along
+            hipLaunchKernelGGL((k_radix_scatter<K, IOTA, DEPTH_BITS, NT, false, CHUNK, RDX, true>), dim3(nblk), dim3(NT), 0, st, kin,
+                               vin, count, dev_count, shift, 0u, hist, tot, nblk, kout, vout, v2in, v2out);
+        else
+            hipLaunchKernelGGL((k_radix_scatter<K, IOTA, DEPTH_BITS, NT, false, CHUNK, RDX>), dim3(nblk), dim3(NT), 0, st, kin, vin, count,
+                               dev_count, shift, 0u, hist, tot, nblk, kout, vout);
         CUGS_LAUNCH_CHECK();
         return 0;
     }
+    if (v2in) return CUGS_EINVAL;
 #ifdef CUGS_DEV
     if (rank_mode() == 1) {               // digit width only matters to the ballot ranking: one instantiation
         hipLaunchKernelGGL((k_radix_scatter<K, IOTA, 8, NT, true, CHUNK>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count,
@@ -977,6 +996,7 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
                 unsigned long long* total_mapped = nullptr, bool three_pass = true, bool prekeyed = false) {
     uint32_t* range_flag = reinterpret_cast<uint32_t*>(ws.total) + 6;
     int rc;
+    bool riding = false;
     if (three_pass) {
         // (1) stable sort of the Gaussians by depth: keys -> dkey[0], three passes [0] -> [1] -> [0] -> [1]
         // prekeyed: cugs_project_forward_keyed has left dkey[0], rect[0] and the range flag in this workspace already
@@ -985,9 +1005,17 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
                                means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[0], ws.rect[0], range_flag);
             CUGS_LAUNCH_CHECK();
         }
-        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+        // prekeyed on an image of up to 127 x 127 tiles: the projection left PACKED rectangles (prect[0]) and they ride
+        // through the passes beside the index, [0] -> [1] -> [0] -> [1]
+        // ... when the passes' workgroups are at most one per CU anyway: the second value stream takes the scatter's LDS
+        // from 68 to 84 KB, i.e. from two resident workgroups per CU to one - free at 1 M Gaussians (245 workgroups on
+        // 256 CUs: sort 0.2285 -> 0.2239 ms, projection -1.5 us, same box), a loss at 6 M (1465 workgroups), where the
+        // gather stays (profiles/r03_j_packed_rect_ride_ab.log)
+        riding = prekeyed && cugs_prect_packable(ntx, nty) && nblocks_for(un, CHUNK_MIN) <= 256u;
+        uint32_t* const* pr = ws.prect;
+        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st, riding ? pr[1] : nullptr, pr[0]))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
     } else {
         // (1) the general route: four passes of 8 bits on the raw depth bits (positive floats order as unsigned ints)
         hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
@@ -1002,7 +1030,7 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
     // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
     hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
-                       ws.blocksum);
+                       ws.blocksum, riding ? static_cast<const uint32_t*>(ws.prect[1]) : static_cast<const uint32_t*>(nullptr));
     CUGS_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_NT), 0, st, ws.blocksum, nfill, ws.total,
                        reinterpret_cast<uint32_t*>(ws.total) + 4, total_mapped, three_pass ? range_flag : static_cast<uint32_t*>(nullptr));
@@ -1019,13 +1047,17 @@ int sort_pairs_dispatch(int tiles, A... args) {
 }  // namespace
 
 int cugs_sort_key_slots(void* workspace, size_t bytes, int64_t n, int width, int height, uint32_t** keys, int4** rect,
-                        uint32_t** range_flag) {
+                        uint32_t** prect, uint32_t** range_flag) {
     if (!workspace || n < 0 || n > 2147483647ll || width < 0 || height < 0) return CUGS_EINVAL;
     if ((width + CUGS_TILE - 1) / CUGS_TILE > 32767 || (height + CUGS_TILE - 1) / CUGS_TILE > 32767) return CUGS_EOVERFLOW;
     SortWsN ws = carve_n(workspace, n);
     if (bytes < ws.bytes) return CUGS_EWORKSPACE;
     *keys = ws.dkey[0];
-    *rect = ws.rect[0];
+    // the same rule queue_count applies when it picks up what the projection left (prekeyed)
+    const bool packed = cugs_prect_packable((width + CUGS_TILE - 1) / CUGS_TILE, (height + CUGS_TILE - 1) / CUGS_TILE) &&
+                        nblocks_for(n, CHUNK_MIN) <= 256u;
+    *rect = packed ? nullptr : ws.rect[0];
+    *prect = packed ? ws.prect[0] : nullptr;
     *range_flag = reinterpret_cast<uint32_t*>(ws.total) + 6;
     return 0;
 }
