@@ -3,7 +3,8 @@ Runs the config-3 step a few hundred times, timing every host-side call of the s
 which one call took more than 3 ms: which call it was, and what the caching allocator / the HIP runtime did across it
 (device allocations, segments, reserved bytes).  A blocked KERNEL LAUNCH with no allocator activity points at the HIP
 runtime's own pools (kernarg / signal / command buffers); a hipMalloc shows as num_device_alloc moving.
-    python tools/stall_trace.py [steps=300] [prealloc_mb=0]
+    python tools/stall_trace.py [steps=300] [prealloc_mb=0] [events=0]
+events = 1: six timing events recorded around the stages of every 4th step, as bench.py does.
 prealloc_mb > 0: reserve-and-release that much device memory through the caching allocator first (does pre-growing the
 allocator's pool remove the stall?)."""
 import os
@@ -20,6 +21,8 @@ import __graft_entry__ as ge   # noqa: E402
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     prealloc = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    with_events = len(sys.argv) > 3 and sys.argv[3] == "1"
+    kept_events = []
     pkg = ge.load_package()
     R = pkg.rasterizer
     dev = torch.device("cuda:0")
@@ -54,6 +57,10 @@ def main():
             marks.append((name, (now - t) * 1e3))
             t = now
         t_step = t
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if (with_events and k % 4 == 0) else None
+        if ev:
+            ev[0].record()
+            lap("create + record events")
         proj = R.project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, cam, 3,
                                    1.0, key_sort=True)
         lap("project_gaussians")
@@ -78,6 +85,15 @@ def main():
                                 model.sh_coeffs, proj.radii, cam, 3, 1.0, grad_accum=rb.grad_accum,
                                 colour_gate=proj.colour_gate, dL_dmeans_2d_out=d_means)
         lap("project_backward")
+        if ev:
+            for e in ev[1:]:
+                e.record()
+            kept_events.append(ev)
+            if len(kept_events) > 8:                     # read some back, as bench.py does at the end
+                old = kept_events.pop(0)
+                old[-1].synchronize()
+                _ = old[0].elapsed_time(old[-1])
+            lap("record + read events")
         del proj, srt, fwd, rb, pb, accum, d_means
         lap("free")
         total = (time.perf_counter() - t_step) * 1e3
