@@ -66,10 +66,12 @@ static inline CamArgs cugs_make_cam_args(const cugs_camera* c, float scale_modif
 // Internal (not part of the C ABI): where the sort's N-level workspace keeps the per-Gaussian depth keys, tile
 // rectangles and the range flag of its three-pass depth ordering (sort.hip: SortWsN), for the projection kernel that
 // fills them in passing (cugs_project_forward_keyed).  CUGS_EWORKSPACE if `bytes` is too small for n Gaussians.
+// *zero / *nzero: dwords the key kernel must clear for the sort (the depth passes' super-block tables, sort.hip).
 // Exactly one of *rect / *prect comes back non-null: prect (one packed dword per Gaussian, cugs_gaussian_math.h:
 // pack_rect) for images of up to 127 x 127 tiles, the 16-byte records otherwise.
 int cugs_sort_key_slots(void* workspace, size_t bytes, int64_t n, int width, int height, uint32_t** keys, int4** rect,
-                        uint32_t** prect, uint32_t** range_flag) __attribute__((visibility("hidden")));
+                        uint32_t** prect, uint32_t** range_flag, uint32_t** zero, uint32_t* nzero)
+    __attribute__((visibility("hidden")));
 
 // XCD-aware bijective block remap (cdna_hip_programming.md T1): blocks b and b+8 share an XCD,
 // so give each XCD a contiguous run of work items (neighbouring tiles share Gaussians -> L2 hits).

@@ -86,6 +86,7 @@ struct ProjPtrs {
     float* opacities_act; float* rgb; float* packed; uint8_t* colour_gate;
     // cugs_project_forward_keyed: the sort's depth keys / tile rectangles / range flag (its N-level workspace), or null
     uint32_t* sort_keys; int4* sort_rect; uint32_t* sort_prect; uint32_t* sort_range_flag;
+    uint32_t* sort_zero; uint32_t sort_nzero;          // dwords to clear for the sort (its depth passes' super tables)
 };
 
 // PART: 0 = the whole projection (cugs_project_forward[_keyed]); 1 = the GEOMETRY half - everything that does not need
@@ -103,6 +104,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_forward(int64_t n, int d
 
     const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
     const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
+    // housekeeping for the sort this launch keys (cugs_project_forward_keyed): every thread of the grid, live or not
+    for (uint32_t z = blockIdx.x * CUGS_BLOCK + threadIdx.x; z < p.sort_nzero; z += gridDim.x * CUGS_BLOCK) p.sort_zero[z] = 0u;
     // this thread's geometry inputs are requested before the SH tile, so that all of a workgroup's reads
     // are in flight together (one HBM latency per workgroup, not one per phase)
     const int64_t idx = base + threadIdx.x;
@@ -428,10 +431,10 @@ int project_forward_impl(int64_t n, int num_coeffs, int active_degree,
 
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
     ProjPtrs p{positions, rotations, scales, opacities, sh_coeffs, means_2d, depths, cov_2d_inv,
-               radii, tiles_touched, opacities_act, rgb, packed, colour_gate, nullptr, nullptr, nullptr, nullptr};
+               radii, tiles_touched, opacities_act, rgb, packed, colour_gate, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
     if (sort_workspace) {
         int rc = cugs_sort_key_slots(sort_workspace, sort_workspace_bytes, n, camera_host->width, camera_host->height,
-                                     &p.sort_keys, &p.sort_rect, &p.sort_prect, &p.sort_range_flag);
+                                     &p.sort_keys, &p.sort_rect, &p.sort_prect, &p.sort_range_flag, &p.sort_zero, &p.sort_nzero);
         if (rc) return rc;
     }
     const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rotations) && cugs_aligned16(rgb) &&
@@ -489,10 +492,10 @@ extern "C" int cugs_project_forward_geometry(int64_t n, const float* positions, 
     if (n > (int64_t)2147483647) return CUGS_EOVERFLOW;
     const CamArgs cam = cugs_make_cam_args(camera_host, scale_modifier);
     ProjPtrs p{positions, rotations, scales, opacities, nullptr, means_2d, depths, cov_2d_inv, radii, tiles_touched,
-               opacities_act, nullptr, packed, nullptr, nullptr, nullptr, nullptr, nullptr};
+               opacities_act, nullptr, packed, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
     if (sort_workspace) {
         int rc = cugs_sort_key_slots(sort_workspace, sort_workspace_bytes, n, camera_host->width, camera_host->height,
-                                     &p.sort_keys, &p.sort_rect, &p.sort_prect, &p.sort_range_flag);
+                                     &p.sort_keys, &p.sort_rect, &p.sort_prect, &p.sort_range_flag, &p.sort_zero, &p.sort_nzero);
         if (rc) return rc;
     }
     const bool aligned = cugs_aligned16(rotations) && cugs_aligned16(cov_2d_inv) &&
@@ -513,7 +516,7 @@ extern "C" int cugs_project_forward_colour(int64_t n, int num_coeffs, int active
     if (n > (int64_t)2147483647) return CUGS_EOVERFLOW;
     const CamArgs cam = cugs_make_cam_args(camera_host, 1.0f);                                 // the colour needs no scale
     ProjPtrs p{positions, nullptr, nullptr, nullptr, sh_coeffs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rgb,
-               packed, colour_gate, nullptr, nullptr, nullptr, nullptr};
+               packed, colour_gate, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
     const bool aligned = cugs_aligned16(sh_coeffs) && cugs_aligned16(rgb);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (num_coeffs) {

@@ -62,7 +62,9 @@ struct SortWsN {
     uint32_t* prect[2];          // the same record packed into a dword (pack_rect), riding through the depth passes  [n]
     uint32_t* tot;               // [RADIX_DEPTH]
     uint32_t* blocksum;          // per FILL_CHUNK block pair counts   [nfill + 2]
-    uint32_t* hist;              // [RADIX_DEPTH][nblk_n] digit-major
+    uint32_t* hist;              // [nblk_n][RADIX_DEPTH] block-major digit counts of the current depth pass
+    uint32_t* sup;               // SUP_TABLES tables [nsb][RADIX_DEPTH]: the same counts summed per super-block, one table per pass
+    uint32_t sup_entries;        // dwords in one table
     uint32_t* colhist;           // [RADIX][ncol] pairs per (tile column, COL_CHUNK block), as counted
     uint32_t* colscan;           // ... and scanned along each column's row
     size_t bytes;
@@ -70,9 +72,39 @@ struct SortWsN {
 struct SortWsP {
     void* ptile[2];              // tile id per pair (u16 when the tile count allows, else u32), ping-pong [P]
     uint32_t* pidx[2];           // Gaussian index per pair            [P]
-    uint32_t* hist;              // [RADIX][nblk_p]
+    uint32_t* hist;              // [nblk_p][RADIX] block-major
+    uint32_t* sup;               // SUP_TABLES tables [nsb][RADIX], one per pair-level pass
+    uint32_t sup_entries;
     size_t bytes;
 };
+
+// Scatter offsets without a scan kernel (round 3), for passes of up to SCANFREE_MAX_BLOCKS workgroups.  A radix pass
+// needs, per workgroup b and digit d, the number of items with digit d in the workgroups before b, and the digit totals.
+// Round 2 got them from a third kernel per pass (k_radix_scan_rows over a digit-major table): ~5 us of kernel boundary
+// for a few microseconds of work, five times a frame.  Now the histogram kernel writes its counts BLOCK-major (one
+// contiguous row per workgroup) and adds them into a per-super-block table (one row per SB workgroups; atomics on a
+// table zeroed by an earlier kernel of the stream: SB adds per address), and every scatter workgroup sums, with coalesced
+// row loads issued at its very start and shared out over all its threads: the super rows before its own (<= nblk / SB),
+// the block rows of its own super-block before it (< SB), and all super rows for the digit totals.
+// Same box, config 3: sort 0.2295 -> 0.2099 ms (with the packed rectangles riding along).  What it costs is the row
+// sums at the head of every scatter workgroup: (nblk / SB + SB) / GRP loads per thread, GRP = threads per digit.  Beyond
+// SCANFREE_MAX_LOADS of them the third kernel stays (6 M Gaussians: 43 per thread in the depth passes, sort +17 us; 40 M
+// pairs: +70-100 us, or - with a third table level - thousands of atomics per address at ~15 ns each;
+// profiles/r03_m_scanfree_ab.log).
+constexpr int SUP_TABLES = 4;                     // passes that may follow one zeroing: 4 depth passes (general route) / 4 pair passes (32-bit tile ids)
+constexpr uint32_t SCANFREE_MAX_BLOCKS = 4096u, SCANFREE_MAX_LOADS = 26u;
+inline uint32_t sup_block(uint32_t nblk) { return nblk <= 512u ? 16u : 64u; }
+// grp: threads per digit of the pass's scatter workgroups (NT >> digit bits)
+inline bool scan_free(uint32_t nblk, uint32_t grp) {
+    const uint32_t sb = sup_block(nblk);
+    return nblk <= SCANFREE_MAX_BLOCKS && ((nblk + sb - 1u) / sb + sb) <= SCANFREE_MAX_LOADS * grp;
+}
+inline uint32_t sup_rows(uint32_t nblk, uint32_t grp) { return scan_free(nblk, grp) ? (nblk + sup_block(nblk) - 1u) / sup_block(nblk) : 0u; }
+// most rows any nblk' <= nblk can need: the workspace is carved for a capacity
+inline uint32_t sup_rows_bound(uint32_t nblk) { return (nblk < SCANFREE_MAX_BLOCKS ? nblk : SCANFREE_MAX_BLOCKS) / 16u + 4u; }
+// dwords of ONE table for a pass over nblk workgroups with rows of rdx digits: the tables of a sort lie back to back at
+// this stride, and that much (x the number of passes) is what the zeroing kernel clears
+inline uint32_t sup_used(uint32_t nblk, int rdx, uint32_t grp) { return (uint32_t)rdx * sup_rows(nblk, grp); }
 
 struct Carver {
     char* base; size_t off = 0;
@@ -94,6 +126,8 @@ SortWsN carve_n(void* base, int64_t n) {
     w.tot = c.take<uint32_t>(RADIX_DEPTH);
     w.blocksum = c.take<uint32_t>((size_t)nblocks_for(n, FILL_CHUNK) + 2);
     w.hist = c.take<uint32_t>((size_t)RADIX_DEPTH * (nblocks_for(n, CHUNK_MIN) + 1));
+    w.sup_entries = (uint32_t)RADIX_DEPTH * sup_rows_bound(nblocks_for(n, CHUNK_MIN));
+    w.sup = c.take<uint32_t>((size_t)SUP_TABLES * w.sup_entries);
     w.colhist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
     w.colscan = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
     w.bytes = c.off;
@@ -105,6 +139,8 @@ SortWsP carve_p(void* base, int64_t pairs) {
     for (int i = 0; i < 2; ++i) w.ptile[i] = c.take<uint32_t>((size_t)pairs);     // sized for the u32 case
     for (int i = 0; i < 2; ++i) w.pidx[i] = c.take<uint32_t>((size_t)pairs);
     w.hist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(pairs, CHUNK_MIN) + 1));
+    w.sup_entries = (uint32_t)RADIX * sup_rows_bound(nblocks_for(pairs, CHUNK_MIN));
+    w.sup = c.take<uint32_t>((size_t)SUP_TABLES * w.sup_entries);
     w.bytes = c.off;
     return w;
 }
@@ -158,8 +194,10 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_depth_keys_rect(uint32_t n, cons
                                                                 int img_h, int ntx, int nty,
                                                                 uint32_t* __restrict__ keys,
                                                                 int4* __restrict__ rect,
-                                                                uint32_t* __restrict__ range_flag) {
+                                                                uint32_t* __restrict__ range_flag,
+                                                                uint32_t* __restrict__ zero, uint32_t nzero) {
     const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
+    for (uint32_t z = i; z < nzero; z += gridDim.x * CUGS_BLOCK) zero[z] = 0u;     // the depth passes' super tables
     if (i >= n) return;
     const int t = tiles[i];
     const int radius = t > 0 ? radii[i] : 0;
@@ -187,7 +225,7 @@ template <typename K, int NT, int CHUNK, int RDX = RADIX>
 __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, uint32_t count_or_cap,
                                                    const unsigned long long* __restrict__ dev_count, int shift,
                                                    uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
-                                                   uint32_t* __restrict__ ctl) {
+                                                   uint32_t* __restrict__ ctl, uint32_t* __restrict__ sup, uint32_t sb) {
     const uint32_t count = live_count(count_or_cap, dev_count);
     constexpr int PER = CHUNK / NT;                           // consecutive keys per thread (order is irrelevant here)
     constexpr int NWORDS = PER * (int)sizeof(K) / 4;          // ... fetched as dwords in 16- or 8-byte loads
@@ -229,7 +267,15 @@ __global__ __launch_bounds__(NT) void k_radix_hist(const K* __restrict__ keys, u
             atomicAdd(&s_cnt[((uint32_t)keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < RDX) hist[threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
+    if (threadIdx.x < RDX) {
+        const uint32_t c = s_cnt[threadIdx.x];
+        if (sup) {                                                              // scan-free pass (kernel-uniform)
+            hist[(size_t)blockIdx.x * RDX + threadIdx.x] = c;                   // block-major: one contiguous row
+            if (c) atomicAdd(&sup[(size_t)(blockIdx.x / sb) * RDX + threadIdx.x], c);
+        } else {
+            hist[(size_t)threadIdx.x * nblk + blockIdx.x] = c;                  // digit-major, for k_radix_scan_rows
+        }
+    }
 }
 
 // Block d: exclusive scan of row d of hist into `out` (may be hist itself); tot[d] = row sum.
@@ -272,7 +318,8 @@ template <typename K, bool IOTA, int NB, int NT, bool ARANK, int CHUNK, int RDX 
 __global__ __launch_bounds__(NT) void k_radix_scatter(
     const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t count_or_cap,
     const unsigned long long* __restrict__ dev_count, int shift, uint32_t mask_rt, const uint32_t* __restrict__ hist,
-    const uint32_t* __restrict__ tot, uint32_t nblk, K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+    const uint32_t* __restrict__ sup, uint32_t sb, const uint32_t* __restrict__ tot, uint32_t nblk,
+    K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
     const uint32_t* __restrict__ vals2_in = nullptr, uint32_t* __restrict__ vals2_out = nullptr) {
     const uint32_t mask = ARANK ? mask_rt : ((1u << NB) - 1u);       // the ballot ranking needs the width at compile time
     const uint32_t count = live_count(count_or_cap, dev_count);
@@ -293,8 +340,37 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
     const uint32_t wbase = bbase + wave * SLICE;
     const uint32_t count_blk = min((uint32_t)CHUNK, count - bbase);
 
+    // Global offsets of this workgroup's digit runs (see the note at sup_block): thread t takes digit t % RDX and every
+    // (NT / RDX)-th row, partial sums meet in LDS further down.  The loads go out first thing and are consumed after the
+    // local ranking.  Rows of blocks beyond the live count hold zeros (their histogram workgroups wrote them).
+    constexpr int ND = ARANK ? RDX : (1 << NB);              // digits that can be non-zero (the rows are RDX wide)
+    constexpr int GRP = NT / ND;                             // threads per digit
+    uint32_t pre = 0u, totd = 0u;
+    if (sup) {                                               // scan-free pass (kernel-uniform)
+        const uint32_t d = tid % ND, part = tid / ND;
+        const uint32_t mysb = blockIdx.x / sb, nsb = (nblk + sb - 1u) / sb;
+#pragma unroll 4
+        for (uint32_t r = part; r < nsb; r += GRP) {             // super rows: totals, and the rows before mine
+            const uint32_t v = sup[(size_t)r * RDX + d];
+            totd += v;
+            pre += (r < mysb) ? v : 0u;
+        }
+#pragma unroll 4
+        for (uint32_t b2 = mysb * sb + part; b2 < blockIdx.x; b2 += GRP) pre += hist[(size_t)b2 * RDX + d];   // my super-block
+    } else if (tid < RDX) {                                  // k_radix_scan_rows has scanned the digit-major table
+        pre = hist[(size_t)tid * nblk + blockIdx.x];
+        totd = tot[tid];
+    }
+
     for (uint32_t e = tid; e < NW * RDX; e += NT) (&s_lbase[0][0])[e] = 0;
+    if (tid < RDX) { s_gbase[tid] = 0u; s_lstart[tid] = 0u; }     // accumulators of the partial sums (pre, totals)
     __syncthreads();
+    if (sup && GRP > 1) {
+        if (pre) atomicAdd(&s_gbase[tid % ND], pre);
+        if (totd) atomicAdd(&s_lstart[tid % ND], totd);
+    } else if (tid < RDX) {
+        s_gbase[tid] = pre; s_lstart[tid] = totd;
+    }
 
     uint32_t k[PER], v[PER], v2[V2 ? PER : 1];
 #pragma unroll
@@ -316,10 +392,11 @@ __global__ __launch_bounds__(NT) void k_radix_scatter(
 #pragma unroll
             for (int w = 0; w < NW; ++w) cnt += s_lbase[w][tid];
         }
-        const uint32_t dig_base = block_exclusive_scan<NW>(dig ? tot[tid] : 0u, s_tmp, nullptr);   // global digit start
+        const uint32_t before = dig ? s_gbase[tid] : 0u;                                           // digit d in the workgroups before this one
+        const uint32_t dig_base = block_exclusive_scan<NW>(dig ? s_lstart[tid] : 0u, s_tmp, nullptr);   // global digit start
         const uint32_t lstart = block_exclusive_scan<NW>(cnt, s_tmp, nullptr);                     // local digit start
         if (dig) {
-            s_gbase[tid] = dig_base + hist[tid * nblk + blockIdx.x];
+            s_gbase[tid] = dig_base + before;
             s_lstart[tid] = lstart;
             uint32_t run = lstart;
 #pragma unroll
@@ -486,7 +563,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     uint32_t n, uint32_t pairs_or_cap, const unsigned long long* __restrict__ dev_count,
     const uint32_t* __restrict__ order, const int4* __restrict__ rect_sorted, int ntx,
     const uint32_t* __restrict__ blocksum, K* __restrict__ ptile, uint32_t* __restrict__ pidx,
-    uint32_t* __restrict__ zero_pairs, int32_t* __restrict__ tile_ranges, uint32_t range_dwords) {
+    uint32_t* __restrict__ zero_pairs, int32_t* __restrict__ tile_ranges, uint32_t range_dwords,
+    uint32_t* __restrict__ sup_zero, uint32_t nsup) {
     constexpr int WIN = 4 * CUGS_WAVE;                               // output slots per wave iteration
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_off[CUGS_BLOCK + 1];
@@ -496,6 +574,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_fill_pairs(
     const uint32_t total_pairs = live_count(pairs_or_cap, dev_count);
     for (uint32_t z = blockIdx.x * CUGS_BLOCK + threadIdx.x; z < range_dwords; z += gridDim.x * CUGS_BLOCK)
         tile_ranges[z] = 0;
+    for (uint32_t z = blockIdx.x * CUGS_BLOCK + threadIdx.x; z < nsup; z += gridDim.x * CUGS_BLOCK)
+        sup_zero[z] = 0u;                                            // the pair passes' super tables (radix_pass)
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t i = blockIdx.x * FILL_CHUNK + tid;
     uint32_t g = 0, t = 0;
@@ -597,8 +677,11 @@ __global__ __launch_bounds__(COL_CHUNK) void k_col_emit(
     const uint32_t* __restrict__ order, const int4* __restrict__ rect_sorted,
     const uint32_t* __restrict__ colscan, const uint32_t* __restrict__ coltot, uint32_t nblk,
     uint16_t* __restrict__ ptile, uint32_t* __restrict__ pidx,
-    uint32_t* __restrict__ zero_pairs, int32_t* __restrict__ tile_ranges, uint32_t range_dwords) {
+    uint32_t* __restrict__ zero_pairs, int32_t* __restrict__ tile_ranges, uint32_t range_dwords,
+    uint32_t* __restrict__ sup_zero, uint32_t nsup) {
     constexpr int NT = COL_CHUNK, NW = COL_WAVES;
+    for (uint32_t z = blockIdx.x * COL_CHUNK + threadIdx.x; z < nsup; z += gridDim.x * COL_CHUNK)
+        sup_zero[z] = 0u;                                            // the row pass's super table (radix_pass)
     constexpr int NWORD = NT / 32;                                   // bit-matrix words per column
     constexpr int NC = RADIX + 1, ZCOL = RADIX;                      // tile columns + the zero-slot pseudo column
     constexpr int NCP = RADIX + 4;
@@ -866,23 +949,28 @@ constexpr int rank_mode() { return 0; }            // ballot ranking: defined by
 
 template <typename K, bool IOTA, int NT, int CHUNK, int RDX = RADIX>
 int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned long long* dev_count, int shift, int bits,
-               uint32_t* hist, uint32_t* tot, K* kout, uint32_t* vout, bool hist_done, uint32_t* ctl, hipStream_t st,
+               uint32_t* hist, uint32_t* sup, uint32_t* tot, K* kout, uint32_t* vout, uint32_t* ctl, hipStream_t st,
                const uint32_t* v2in = nullptr, uint32_t* v2out = nullptr) {
+    // `sup`: this pass's super-block table, ZEROED by an earlier kernel of the stream (the key kernel / the projection for
+    // the depth passes, the pair emission for the pair passes); used for passes of up to SCANFREE_MAX_BLOCKS workgroups
     const uint32_t nblk = nblocks_for(count, CHUNK);
-    if (!hist_done) {
-        hipLaunchKernelGGL((k_radix_hist<K, NT, CHUNK, RDX>), dim3(nblk), dim3(NT), 0, st, kin, count, dev_count, shift,
-                           (1u << bits) - 1u, hist, nblk, ctl);
+    const uint32_t sb = sup_block(nblk);
+    static_assert(NT % RDX == 0, "whole thread groups per digit");
+    if (!scan_free(nblk, (uint32_t)NT >> bits)) sup = nullptr;
+    hipLaunchKernelGGL((k_radix_hist<K, NT, CHUNK, RDX>), dim3(nblk), dim3(NT), 0, st, kin, count, dev_count, shift,
+                       (1u << bits) - 1u, hist, nblk, ctl, sup, sb);
+    CUGS_LAUNCH_CHECK();
+    if (!sup) {
+        hipLaunchKernelGGL(k_radix_scan_rows, dim3(RDX), dim3(CUGS_BLOCK), 0, st, hist, hist, nblk, tot);
         CUGS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_radix_scan_rows, dim3(RDX), dim3(CUGS_BLOCK), 0, st, hist, hist, nblk, tot);
-    CUGS_LAUNCH_CHECK();
     if constexpr (RDX == RADIX_DEPTH) {                    // the 9-bit passes of the depth sort: ballot ranking only
         if (v2in)                                          // the packed tile rectangle rides along
             hipLaunchKernelGGL((k_radix_scatter<K, IOTA, DEPTH_BITS, NT, false, CHUNK, RDX, true>), dim3(nblk), dim3(NT), 0, st, kin,
-                               vin, count, dev_count, shift, 0u, hist, tot, nblk, kout, vout, v2in, v2out);
+                               vin, count, dev_count, shift, 0u, hist, sup, sb, tot, nblk, kout, vout, v2in, v2out);
         else
             hipLaunchKernelGGL((k_radix_scatter<K, IOTA, DEPTH_BITS, NT, false, CHUNK, RDX>), dim3(nblk), dim3(NT), 0, st, kin, vin, count,
-                               dev_count, shift, 0u, hist, tot, nblk, kout, vout);
+                               dev_count, shift, 0u, hist, sup, sb, tot, nblk, kout, vout);
         CUGS_LAUNCH_CHECK();
         return 0;
     }
@@ -890,14 +978,14 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
 #ifdef CUGS_DEV
     if (rank_mode() == 1) {               // digit width only matters to the ballot ranking: one instantiation
         hipLaunchKernelGGL((k_radix_scatter<K, IOTA, 8, NT, true, CHUNK>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count,
-                           shift, (1u << bits) - 1u, hist, tot, nblk, kout, vout);
+                           shift, (1u << bits) - 1u, hist, sup, sb, tot, nblk, kout, vout);
         CUGS_LAUNCH_CHECK();
         return 0;
     }
 #endif
 #define CUGS_SCATTER(NB)                                                                                          \
     hipLaunchKernelGGL((k_radix_scatter<K, IOTA, NB, NT, false, CHUNK>), dim3(nblk), dim3(NT), 0, st, kin, vin, count, dev_count, \
-                       shift, 0u, hist, tot, nblk, kout, vout)
+                       shift, 0u, hist, sup, sb, tot, nblk, kout, vout)
     switch (bits) {
         case 1: CUGS_SCATTER(1); break;
         case 2: CUGS_SCATTER(2); break;
@@ -958,10 +1046,11 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
             hipLaunchKernelGGL(k_radix_scan_rows, dim3(RADIX), dim3(CUGS_BLOCK), 0, st, ws.colhist, ws.colscan, ncol, ws.tot);
             CUGS_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_col_emit, dim3(ncol), dim3(COL_CHUNK), 0, st, un, up, dev_count, order, ws.rect[1],
-                               ws.colscan, ws.tot, ncol, tk[0], tv[0], ctl, tile_ranges, (uint32_t)(2 * tiles));
+                               ws.colscan, ws.tot, ncol, tk[0], tv[0], ctl, tile_ranges, (uint32_t)(2 * tiles), wp.sup,
+                               sup_used(nblocks_for(up, CHUNK_PAIR), RADIX, 512u >> tile_bits(nty)));
             CUGS_LAUNCH_CHECK();
-            int rc = radix_pass<K, false, 512, CHUNK_PAIR>(tk[0], tv[0], up, dev_count, 8, tile_bits(nty), wp.hist, ws.tot,
-                                                           tk[1], vals_final, false, ctl, st);
+            int rc = radix_pass<K, false, 512, CHUNK_PAIR>(tk[0], tv[0], up, dev_count, 8, tile_bits(nty), wp.hist, wp.sup,
+                                                           ws.tot, tk[1], vals_final, ctl, st);
             if (rc) return rc;
             hipLaunchKernelGGL((k_tile_ranges<K, true>), dim3(nblocks_for(up, CUGS_BLOCK * 8)), dim3(CUGS_BLOCK), 0, st, up,
                                dev_count, tk[1], (uint32_t)ntx, values_sorted, depths, tile_ranges, keys_sorted, ctl + 1);
@@ -969,16 +1058,25 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
             return 0;
         }
     }
+    if (npass > SUP_TABLES) return CUGS_EINVAL;
+    // each pass's super table (if that pass runs scan-free: radix_pass applies the same rule), back to back
+    const uint32_t nblk_p = nblocks_for(up, CHUNK_PAIR);
+    uint32_t sup_off[SUP_TABLES + 1] = {0u};
+    for (int p = 0; p < npass; ++p) {
+        const int shift = p * per;
+        const int b = (bits - shift) < per ? (bits - shift) : per;
+        sup_off[p + 1] = sup_off[p] + sup_used(nblk_p, RADIX, 512u >> b);
+    }
     hipLaunchKernelGGL((k_fill_pairs<K>), dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, up, dev_count, order, ws.rect[1], ntx,
-                       ws.blocksum, tk[0], tv[0], ctl, tile_ranges, (uint32_t)(2 * tiles));
+                       ws.blocksum, tk[0], tv[0], ctl, tile_ranges, (uint32_t)(2 * tiles), wp.sup, sup_off[npass]);
     CUGS_LAUNCH_CHECK();
     int cur = 0, rc;
     for (int p = 0; p < npass; ++p) {
         const int shift = p * per;
         const int b = (bits - shift) < per ? (bits - shift) : per;
         uint32_t* vout = (p == npass - 1) ? vals_final : tv[cur ^ 1];
-        rc = radix_pass<K, false, 512, CHUNK_PAIR>(tk[cur], tv[cur], up, dev_count, shift, b, wp.hist, ws.tot, tk[cur ^ 1], vout, false,
-                                       p == 0 ? ctl : nullptr, st);   // 512 threads: measured best of 256/512/1024
+        rc = radix_pass<K, false, 512, CHUNK_PAIR>(tk[cur], tv[cur], up, dev_count, shift, b, wp.hist, wp.sup + sup_off[p], ws.tot,
+                                                   tk[cur ^ 1], vout, p == 0 ? ctl : nullptr, st);   // 512 threads: measured best of 256/512/1024
         if (rc) return rc;
         cur ^= 1;
     }
@@ -1002,7 +1100,8 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
         // prekeyed: cugs_project_forward_keyed has left dkey[0], rect[0] and the range flag in this workspace already
         if (!prekeyed) {
             hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
-                               means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[0], ws.rect[0], range_flag);
+                               means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[0], ws.rect[0], range_flag,
+                               ws.sup, 3u * sup_used(nblocks_for(un, CHUNK_MIN), RADIX_DEPTH, 1024u >> DEPTH_BITS));
             CUGS_LAUNCH_CHECK();
         }
         // prekeyed on an image of up to 127 x 127 tiles: the projection left PACKED rectangles (prect[0]) and they ride
@@ -1013,19 +1112,23 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
         // gather stays (profiles/r03_j_packed_rect_ride_ab.log)
         riding = prekeyed && cugs_prect_packable(ntx, nty) && nblocks_for(un, CHUNK_MIN) <= 256u;
         uint32_t* const* pr = ws.prect;
-        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st, riding ? pr[1] : nullptr, pr[0]))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
+        const uint32_t used = sup_used(nblocks_for(un, CHUNK_MIN), RADIX_DEPTH, 1024u >> DEPTH_BITS);
+        uint32_t* const sup0 = ws.sup, *const sup1 = ws.sup + used, *const sup2 = ws.sup + 2 * (size_t)used;
+        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, sup0, ws.tot, ws.dkey[1], ws.dval[1], nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, sup1, ws.tot, ws.dkey[0], ws.dval[0], nullptr, st, riding ? pr[1] : nullptr, pr[0]))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, sup2, ws.tot, ws.dkey[1], ws.dval[1], nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
     } else {
         // (1) the general route: four passes of 8 bits on the raw depth bits (positive floats order as unsigned ints)
         hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
                            means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[1], ws.rect[0],
-                           static_cast<uint32_t*>(nullptr));
+                           static_cast<uint32_t*>(nullptr), ws.sup, 4u * sup_used(nblocks_for(un, CHUNK_MIN), RADIX, 1024u >> 8));
         CUGS_LAUNCH_CHECK();
-        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN>(ws.dkey[1], nullptr, un, nullptr, 0, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 8, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[1], ws.dval[1], un, nullptr, 16, 8, ws.hist, ws.tot, ws.dkey[0], ws.dval[0], false, nullptr, st))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, ws.tot, ws.dkey[1], ws.dval[1], false, nullptr, st))) return rc;
+        uint32_t* sp[SUP_TABLES];
+        for (int t = 0; t < SUP_TABLES; ++t) sp[t] = ws.sup + (size_t)t * sup_used(nblocks_for(un, CHUNK_MIN), RADIX, 1024u >> 8);
+        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN>(ws.dkey[1], nullptr, un, nullptr, 0, 8, ws.hist, sp[0], ws.tot, ws.dkey[0], ws.dval[0], nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 8, 8, ws.hist, sp[1], ws.tot, ws.dkey[1], ws.dval[1], nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[1], ws.dval[1], un, nullptr, 16, 8, ws.hist, sp[2], ws.tot, ws.dkey[0], ws.dval[0], nullptr, st))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, sp[3], ws.tot, ws.dkey[1], ws.dval[1], nullptr, st))) return rc;
     }
     // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
@@ -1047,7 +1150,7 @@ int sort_pairs_dispatch(int tiles, A... args) {
 }  // namespace
 
 int cugs_sort_key_slots(void* workspace, size_t bytes, int64_t n, int width, int height, uint32_t** keys, int4** rect,
-                        uint32_t** prect, uint32_t** range_flag) {
+                        uint32_t** prect, uint32_t** range_flag, uint32_t** zero, uint32_t* nzero) {
     if (!workspace || n < 0 || n > 2147483647ll || width < 0 || height < 0) return CUGS_EINVAL;
     if ((width + CUGS_TILE - 1) / CUGS_TILE > 32767 || (height + CUGS_TILE - 1) / CUGS_TILE > 32767) return CUGS_EOVERFLOW;
     SortWsN ws = carve_n(workspace, n);
@@ -1059,6 +1162,8 @@ int cugs_sort_key_slots(void* workspace, size_t bytes, int64_t n, int width, int
     *rect = packed ? nullptr : ws.rect[0];
     *prect = packed ? ws.prect[0] : nullptr;
     *range_flag = reinterpret_cast<uint32_t*>(ws.total) + 6;
+    *zero = ws.sup;                                // the key kernel also clears the depth passes' super tables
+    *nzero = 3u * sup_used(nblocks_for(n, CHUNK_MIN), RADIX_DEPTH, 1024u >> DEPTH_BITS);       // the three passes of the fast depth route
     return 0;
 }
 
