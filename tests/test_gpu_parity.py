@@ -84,6 +84,29 @@ def test_sort_parity_bit_exact(pkg, orc, dev, n, w, h, mu_s):
 
 
 @pytest.mark.parametrize("mu_s,dense", [(-4.6, False), (-3.2, True)])
+@pytest.mark.parametrize("n,expect", [(230_000, "16"), (300_000, "64"), (600_000, "64")])
+def test_render_sort_routes_by_size(pkg, orc, dev, n, expect):
+    """render()'s sort at the sizes where its radix passes change shape (sort.hip: scan_free / sup_block): a pair level of
+    ~470 workgroups (super-blocks of 16), of ~610 and ~1230 (super-blocks of 64); each with the packed rectangles riding
+    through the depth passes (n <= 1 M, 120 x 68 tiles).  (Pair levels beyond 4096 workgroups - the classic three kernels
+    per pass - are the dense full-size view and config 4.)  Pairs, order, ranges and the image against the
+    oracle; the predicted (keyed) route is the one render() takes from its second frame on."""
+    w, h = 1920, 1080
+    arrays, cam = _scene(pkg, n, w, h, 0, seed=n, mu_s=-4.6)
+    ref = oracle_forward(orc, arrays, cam, degree=0)
+    blocks = (ref["total_pairs"] + 4095) // 4096
+    assert {"16": blocks <= 512, "64": 512 < blocks <= 4096}[expect], blocks
+    model = pkg.scene.to_model(arrays, dev)
+    settings = pkg.RenderSettings(active_sh_degree=0)
+    for frame in range(3):                      # blocking route, then twice the keyed / predicted one
+        out = pkg.render(model, cam, settings, for_backward=False)
+        assert out.total_pairs == ref["total_pairs"], frame
+        assert np.array_equal(np_(out.gaussian_indices), ref["values"]), frame
+        assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"]), frame
+        assert np.array_equal(np_(out.n_contrib), ref["n_contrib"]), frame
+        assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32)), frame
+
+
 def test_sort_both_pair_routes(pkg, orc, dev, mu_s, dense):
     """The pair-level sort has two routes to the same permutation: pairs emitted in depth order + two radix passes
     by tile id (sparse views), or pairs emitted in tile-column order + one pass by tile row (>= 13 pairs per
