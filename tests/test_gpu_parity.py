@@ -83,7 +83,6 @@ def test_sort_parity_bit_exact(pkg, orc, dev, n, w, h, mu_s):
     assert np.array_equal(np_(srt.tile_ranges), ref["tile_ranges"])                          # per-tile spans
 
 
-@pytest.mark.parametrize("mu_s,dense", [(-4.6, False), (-3.2, True)])
 @pytest.mark.parametrize("n,expect", [(230_000, "16"), (300_000, "64"), (600_000, "64")])
 def test_render_sort_routes_by_size(pkg, orc, dev, n, expect):
     """render()'s sort at the sizes where its radix passes change shape (sort.hip: scan_free / sup_block): a pair level of
@@ -107,6 +106,7 @@ def test_render_sort_routes_by_size(pkg, orc, dev, n, expect):
         assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32)), frame
 
 
+@pytest.mark.parametrize("mu_s,dense", [(-4.6, False), (-3.2, True)])
 def test_sort_both_pair_routes(pkg, orc, dev, mu_s, dense):
     """The pair-level sort has two routes to the same permutation: pairs emitted in depth order + two radix passes
     by tile id (sparse views), or pairs emitted in tile-column order + one pass by tile row (>= 13 pairs per
