@@ -396,7 +396,7 @@ def parse_rccl_log(paths) -> dict:
     algorithm and a protocol is taken, numeric ids mapped to names.  Returns {collective: ["Ring/Simple", ...]} plus the
     channel count if announced; {} when nothing could be read (then only the raw tail is kept)."""
     import re
-    choices, channels, tail = {}, None, []
+    choices, channels, coll_channels, tail = {}, None, None, []
     pat = re.compile(r"(AllReduce|AllGather|ReduceScatter|Broadcast)\b.*?[Aa]lgo(?:rithm)?\s*[:=]?\s*(\w+).*?[Pp]roto(?:col)?\s*[:=]?\s*(\w+)")
     chan = re.compile(r"(\d+)\s+coll channels|nChannels\s*[:=]?\s*(\d+)|Channel\s+(\d+)/(\d+)")
     for path in paths:
@@ -404,7 +404,7 @@ def parse_rccl_log(paths) -> dict:
             lines = open(path, errors="replace").read().splitlines()
         except OSError:
             continue
-        tail = lines[-5:]
+        tail = [ln for ln in lines if " WARN " not in ln][-5:]
         for ln in lines:
             m = pat.search(ln)
             if m:
@@ -412,12 +412,14 @@ def parse_rccl_log(paths) -> dict:
                 proto = RCCL_PROTOS.get(int(m.group(3)), m.group(3)) if m.group(3).isdigit() else m.group(3)
                 choices.setdefault(m.group(1), set()).add(f"{algo}/{proto}")
             mc = chan.search(ln)
-            if mc:
+            if mc and mc.group(1):                                      # "N coll channels, ..." is the authoritative line
+                coll_channels = max(coll_channels or 0, int(mc.group(1)))
+            elif mc:
                 vals = [int(v) for v in mc.groups() if v]
                 channels = max(channels or 0, max(vals))
     out = {k: sorted(v) for k, v in choices.items()}
-    if channels:
-        out["channels"] = channels
+    if coll_channels or channels:
+        out["channels"] = coll_channels or channels
     if not out and tail:
         out["unparsed_tail"] = [t[-160:] for t in tail]
     return out
@@ -556,9 +558,10 @@ def main():
         # which algorithm / protocol / channel count RCCL picks on this node's xGMI links is the first thing to know when
         # the scaling curve disappoints: its INFO lines go to a per-rank file that rank 0 parses into the JSON line
         rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cugs_bench_rccl_{os.getpid()}_%h_%p.log")
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):      # a box default of WARN/VERSION is
+            os.environ["NCCL_DEBUG"] = "INFO"                                       # replaced; a louder user setting kept
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
-        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()                                    # what RCCL actually sees
@@ -788,7 +791,8 @@ def main():
             logs = _glob.glob(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cugs_bench_rccl_{os.getpid()}_*.log"))
             out["exchange"] = {"mode": exchange["mode"], "compute_only_ms": base,
                                "timed_region_exposed_ms": round(ms_per_step - base, 4) if base is not None else None,
-                               "per_mode": per_mode, "rccl": parse_rccl_log(logs) if logs else None}
+                               "per_mode": per_mode,
+                               "rccl": parse_rccl_log(logs) if logs else {"unparsed_tail": ["no RCCL log file was written"]}}
         need_oracle = n_gpus == 1 and not (args.no_cpu_baseline and args.no_parity)
         orc = ge.load_oracle() if need_oracle else None
         if not args.no_cpu_baseline and n_gpus == 1:      # rank 0 at N=1 only
