@@ -67,6 +67,9 @@ struct SortWsN {
     uint32_t sup_entries;        // dwords in one table
     uint32_t* colhist;           // [RADIX][ncol] pairs per (tile column, COL_CHUNK block), as counted
     uint32_t* colscan;           // ... and scanned along each column's row
+    uint32_t* bin_table;         // direct binning: [rows][tiles] pairs per (workgroup of the depth order, tile), then their prefix
+    uint32_t* bin_ttot;          // [tiles] pairs per tile
+    uint32_t* bin_tbase;         // [tiles + 1] first real pair of each tile; [tiles] = pair total
     size_t bytes;
 };
 struct SortWsP {
@@ -106,6 +109,23 @@ inline uint32_t sup_rows_bound(uint32_t nblk) { return (nblk < SCANFREE_MAX_BLOC
 // this stride, and that much (x the number of passes) is what the zeroing kernel clears
 inline uint32_t sup_used(uint32_t nblk, int rdx, uint32_t grp) { return (uint32_t)rdx * sup_rows(nblk, grp); }
 
+// Direct binning (k_bin_count / k_bin_scan / k_bin_scatter further down): table geometry, needed by the workspace carving.
+constexpr int BIN_TILES_CAP = 10240;              // tiles of the image (k_bin_count's LDS row)
+constexpr uint32_t BIN_GROUP = 4096u, BIN_ROWS_MAX = 512u;
+constexpr int BIN_TTOT_PAD = 12288;                // dwords of the per-tile totals: twelve per thread of k_bin_starts
+// Gaussians per table row (and per workgroup of k_bin_count): measured best of 2048 ... 16384 at 1 M Gaussians.  The route is
+// taken for up to BIN_ROWS_MAX rows = 2 M Gaussians: at 6 M (40 M pairs) it ties with the radix passes (0.83 ms both,
+// profiles/r03_s_direct_binning.log), which stay in charge there.
+inline uint32_t bin_group() {
+#ifdef CUGS_DEV
+    if (const char* e = std::getenv("CUGS_BIN_GROUP")) return (uint32_t)std::atoi(e);   // development build: sweeps (tools/ablate_bin.py)
+#endif
+    return BIN_GROUP;
+}
+inline bool bin_route_n(int64_t n) { return n <= (int64_t)bin_group() * BIN_ROWS_MAX; }
+inline uint32_t bin_rows(uint32_t n) { return (n + bin_group() - 1u) / bin_group(); }
+inline uint32_t bin_table_rows(int64_t n) { return n > 0 && bin_route_n(n) ? bin_rows((uint32_t)n) : 1u; }
+
 struct Carver {
     char* base; size_t off = 0;
     template <typename T> T* take(size_t count) {
@@ -130,6 +150,9 @@ SortWsN carve_n(void* base, int64_t n) {
     w.sup = c.take<uint32_t>((size_t)SUP_TABLES * w.sup_entries);
     w.colhist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
     w.colscan = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
+    w.bin_table = c.take<uint32_t>((size_t)bin_table_rows(n) * BIN_TILES_CAP);
+    w.bin_ttot = c.take<uint32_t>(BIN_TTOT_PAD);
+    w.bin_tbase = c.take<uint32_t>(BIN_TTOT_PAD + 4);
     w.bytes = c.off;
     return w;
 }
@@ -894,6 +917,350 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t pairs_or_ca
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Direct binning (round 3): steps (2)-(4) as ONE counting sort by tile id, for views of up to 2 M Gaussians on images of up
+// to BIN_T_MAX tiles whose per-Gaussian records are the projection's packed rectangles (render()'s route).  The two
+// radix passes over the pairs (emit tile id + index, histogram, scatter, histogram, scatter, range detection: eight
+// launches, every pair written three times and read four) become four launches that write every pair ONCE:
+//   k_bin_count    a workgroup takes a GROUP of 4096 consecutive Gaussians of the depth order and counts, in LDS, how
+//                  many of them cover each tile: row b of the table [groups][tiles];
+//   k_bin_scan     per tile, the exclusive prefix of its column of the table (= where group b's first pair of the tile
+//                  goes inside the tile's list) and the tile's total;
+//   k_bin_starts   the tile totals scanned into tile starts; publishes the pair total and the tile ranges;
+//   k_bin_scatter  a wave per (group, block of 8 x 8 tiles) walks the group's records in depth order and writes each
+//                  pair's Gaussian index straight to  tile start + prefix + pairs of this group written so far.
+// What makes the last kernel a STABLE sort (ties in depth order, bit for bit what the radix passes give): every
+// (group, tile) has exactly one writer, a lane that visits the records in order.
+// Measured, whole sort, same box (tools/ablate_bin.py, profiles/r03_s_direct_binning.log): 1 M Gaussians / 8.4 M pairs
+// 0.200 -> 0.178 ms, 45 M pairs 0.46-0.48 -> 0.355, 100 k Gaussians 0.130 -> 0.119; 6 M Gaussians / 40 M pairs 0.825 vs 0.83
+// (not taken there).  What was tried on the way is in profiles/README.md (a workgroup per group with tile ownership by
+// wave and 64-bit cover words for the ranking: 0.25 ms, latency-bound at one workgroup per CU; a wave per tile row or
+// per band of four rows: 0.23-0.25, instruction-bound on the per-record scalar loop).
+// ------------------------------------------------------------------------------------
+constexpr int BIN_WAVES = 16, BIN_NT = BIN_WAVES * CUGS_WAVE;
+constexpr int BIN_T_MAX = BIN_TILES_CAP;
+inline bool bin_route(int ntx, int nty) {
+    return cugs_prect_packable(ntx, nty) && ntx * nty <= BIN_T_MAX;
+}
+
+// rect: the records in INPUT order (gathered through `order` and packed here, prect_out keeps them for the scatter) unless
+// prect_in holds them in depth order already (they rode through the depth passes).
+// Counting costs FOUR LDS atomics per Gaussian, whatever its size: +1 / -1 at the corners of its rectangle in a grid of
+// differences, then a prefix sum along the rows and one along the columns (a loop over the w x h tiles of each lane's own
+// rectangle keeps a quarter of the lanes busy, and an LDS atomic instruction costs the same ~9 clocks of the CU's LDS
+// pipeline with 15 active lanes as with 64: 33 us at 8.4 pairs per Gaussian, 200 at 45).
+constexpr int BIN_D_MAX = BIN_T_MAX + 2 * CUGS_PRECT_MAX_TILES + 2;   // (ntx + 1) x (nty + 1) differences
+__global__ __launch_bounds__(BIN_NT) void k_bin_count(uint32_t n, uint32_t group, const uint32_t* __restrict__ order,
+                                                      const int4* __restrict__ rect, const uint32_t* __restrict__ prect_in,
+                                                      uint32_t* __restrict__ prect_out, uint32_t ntx, uint32_t nty,
+                                                      uint32_t* __restrict__ table, uint32_t* __restrict__ zero_pairs) {
+    __shared__ int32_t s_d[BIN_D_MAX];
+    __shared__ int32_t s_part[8][128];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t w2 = ntx + 1u, cells = w2 * (nty + 1u);
+    for (uint32_t e = tid; e < cells; e += BIN_NT) s_d[e] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * group;
+    const uint32_t end = min(n, base + group);
+    for (uint32_t i = base + tid; i < end; i += BIN_NT) {
+        uint32_t pr;
+        if (prect_in) {
+            pr = prect_in[i];
+        } else {
+            pr = pack_rect(rect[order[i]]);                           // the one gather per Gaussian
+            prect_out[i] = pr;
+        }
+        if (pr & 0x80000000u) {                                       // no rectangle: nothing, or quirk Q12's zero slots
+            const uint32_t z = pr & 0x7FFFFFFFu;
+            if (z) atomicAdd(zero_pairs, z);
+            continue;
+        }
+        const uint32_t x0 = pr & 127u, y0 = (pr >> 7) & 127u, w = (pr >> 14) & 127u, h = (pr >> 21) & 127u;
+        atomicAdd(&s_d[y0 * w2 + x0], 1);
+        atomicAdd(&s_d[y0 * w2 + x0 + w], -1);
+        atomicAdd(&s_d[(y0 + h) * w2 + x0], -1);
+        atomicAdd(&s_d[(y0 + h) * w2 + x0 + w], 1);
+    }
+    __syncthreads();
+    for (uint32_t row = wave; row < nty; row += BIN_WAVES) {           // prefix along x: a wave per row
+        int32_t carry = 0;
+        for (uint32_t c0 = 0; c0 < ntx; c0 += CUGS_WAVE) {
+            const uint32_t x = c0 + lane;
+            const int32_t v = x < ntx ? s_d[row * w2 + x] : 0;
+            const int32_t inc = (int32_t)wave_inclusive_scan((uint32_t)v) + carry;
+            if (x < ntx) s_d[row * w2 + x] = inc;
+            carry = __shfl(inc, 63);
+        }
+    }
+    __syncthreads();
+    {   // prefix along y: thread = (column, one of eight runs of rows)
+        const uint32_t x = tid & 127u, seg = tid >> 7;
+        const uint32_t rps = (nty + 7u) / 8u;
+        const uint32_t ya = min(nty, seg * rps), yb = min(nty, ya + rps);
+        int32_t sum = 0;
+        if (x < ntx)
+            for (uint32_t y = ya; y < yb; ++y) sum += s_d[y * w2 + x];
+        s_part[seg][x] = sum;
+        __syncthreads();
+        int32_t run = 0;
+        for (uint32_t s2 = 0; s2 < seg; ++s2) run += s_part[s2][x];
+        if (x < ntx)
+            for (uint32_t y = ya; y < yb; ++y) {
+                run += s_d[y * w2 + x];
+                s_d[y * w2 + x] = run;
+            }
+    }
+    __syncthreads();
+    uint32_t* out = table + (size_t)blockIdx.x * (ntx * nty);
+    for (uint32_t row = wave; row < nty; row += BIN_WAVES)
+        for (uint32_t x = lane; x < ntx; x += CUGS_WAVE) out[row * ntx + x] = (uint32_t)s_d[row * w2 + x];
+}
+
+// Workgroup = 64 tiles x 16 runs of table rows.  In place: table[b][t] becomes the number of pairs of tile t in the
+// workgroups before b; ttot[t] = pairs of tile t.  Block 0 also takes the snapshots the scatter works from: the Q12 count
+// k_bin_count has finished adding to (snap[0]; the counter is re-armed) and the depth range flag (snap[1]; re-armed).
+// No grid-wide step here: a workgroup that waits for the others' totals must first make its own visible across the
+// XCDs' L2s (a release fence = an L2 write-back with 8 MB of freshly written table in it: this kernel took 52 us that
+// way); the scatter's workgroups each scan the 8 K tile totals themselves instead (1-2 us, all at once).
+__global__ __launch_bounds__(BIN_NT) void k_bin_scan(uint32_t rows, uint32_t tiles, uint32_t* __restrict__ table,
+                                                     uint32_t* __restrict__ ttot, uint32_t* __restrict__ q12,
+                                                     uint32_t* __restrict__ range_flag, uint32_t* __restrict__ snap) {
+    __shared__ uint32_t s_seg[BIN_WAVES][CUGS_WAVE];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        snap[0] = q12[0]; q12[1] = q12[0]; q12[0] = 0u;
+        snap[1] = *range_flag; *range_flag = 0u;
+    }
+    const uint32_t tl = threadIdx.x & 63u, seg = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * CUGS_WAVE + tl;
+    const uint32_t rps = (rows + BIN_WAVES - 1u) / BIN_WAVES;
+    const uint32_t r0 = min(rows, seg * rps), r1 = min(rows, r0 + rps);
+    uint32_t sum = 0u;
+    if (t < tiles) {
+#pragma unroll 8
+        for (uint32_t r = r0; r < r1; ++r) sum += table[(size_t)r * tiles + t];
+    }
+    s_seg[seg][tl] = sum;
+    __syncthreads();
+    uint32_t pre = 0u, tot = 0u;
+#pragma unroll
+    for (uint32_t s2 = 0; s2 < (uint32_t)BIN_WAVES; ++s2) {
+        const uint32_t v = s_seg[s2][tl];
+        pre += s2 < seg ? v : 0u;
+        tot += v;
+    }
+    if (t < tiles) {
+        uint32_t run = pre;
+#pragma unroll 8
+        for (uint32_t r = r0; r < r1; ++r) {
+            const uint32_t v = table[(size_t)r * tiles + t];
+            table[(size_t)r * tiles + t] = run;
+            run += v;
+        }
+        if (seg == 0u) ttot[t] = tot;
+    }
+}
+
+// One workgroup: the tile totals scanned into tile starts - tbase[t] = where the first REAL pair of tile t goes (tile 0's
+// list begins with the Q12 zero pairs, see k_fill_pairs), tbase[tiles] = the pair total - plus everything
+// k_scan_blocksums publishes on the radix route (the totals, the host's copy) and the tile ranges.
+// predicted: pairs_or_cap is the capacity of the index buffer (else the exact pair count).  When the pairs do not fit
+// (or the depth order is invalid: a key outside the three-pass range) the result is declared invalid through the total,
+// as on the radix route; the scatter then writes nothing (snap[2] = 0) and EVERY range is {0,0}, so that the blend
+// queued behind it does nothing instead of walking an unwritten index buffer.
+__global__ __launch_bounds__(BIN_NT) void k_bin_starts(uint32_t tiles, uint32_t pairs_or_cap, bool predicted,
+                                                       const uint32_t* __restrict__ ttot, uint32_t* __restrict__ snap,
+                                                       uint32_t* __restrict__ tbase, unsigned long long* __restrict__ total,
+                                                       unsigned long long* __restrict__ total_mapped,
+                                                       int32_t* __restrict__ tile_ranges) {
+    __shared__ uint32_t s_tmp[BIN_WAVES];
+    __shared__ unsigned long long s_sum[BIN_WAVES];
+    const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+    // twelve consecutive tiles per thread, fetched as three 16-byte loads (ttot has BIN_TTOT_PAD dwords; entries beyond
+    // `tiles` are whatever the workspace held and are masked)
+    constexpr int PER = BIN_TTOT_PAD / BIN_NT;
+    static_assert(PER == 12 && PER * BIN_NT >= BIN_T_MAX + 1, "three uint4 per thread cover every tile");
+    const uint32_t e0 = tid * PER;
+    uint32_t cnt[PER], part = 0u;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(ttot + e0);
+        const uint4 q0 = src[0], q1 = src[1], q2 = src[2];
+        const uint32_t raw[PER] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+        for (int e = 0; e < PER; ++e) { cnt[e] = (e0 + e < tiles) ? raw[e] : 0u; part += cnt[e]; }
+    }
+    const uint32_t zero = snap[0];
+    const bool bad = snap[1] != 0u;
+    uint32_t run = zero + block_exclusive_scan<BIN_WAVES>(part, s_tmp, nullptr);
+    unsigned long long wide = part;                                   // the grand total in 64 bits (int32 overflow is the host's check)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wide += __shfl_down(wide, d);
+    if (lane == 0u) s_sum[wid] = wide;
+    __syncthreads();
+    unsigned long long pairs = zero;
+#pragma unroll
+    for (int w2 = 0; w2 < BIN_WAVES; ++w2) pairs += s_sum[w2];
+    const bool fits = !bad && (!predicted || pairs <= (unsigned long long)pairs_or_cap);
+    uint32_t st[PER + 1];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) { st[e] = run; run += cnt[e]; }
+    st[PER] = run;
+    if (e0 + PER <= tiles) {                                          // whole 16-byte stores
+        uint4* tb = reinterpret_cast<uint4*>(tbase + e0);
+        tb[0] = make_uint4(st[0], st[1], st[2], st[3]);
+        tb[1] = make_uint4(st[4], st[5], st[6], st[7]);
+        tb[2] = make_uint4(st[8], st[9], st[10], st[11]);
+        int4* tr = reinterpret_cast<int4*>(tile_ranges + 2 * (size_t)e0);
+#pragma unroll
+        for (int e = 0; e < PER; e += 2) {
+            const uint32_t t = e0 + e;
+            const uint32_t ca = fits ? cnt[e] + (t == 0u ? zero : 0u) : 0u, cb = fits ? cnt[e + 1] : 0u;   // {0,0}: sorting.cu:216
+            tr[e / 2] = make_int4(ca ? (int32_t)(t == 0u ? 0u : st[e]) : 0, ca ? (int32_t)st[e + 1] : 0,
+                                  cb ? (int32_t)st[e + 1] : 0, cb ? (int32_t)st[e + 2] : 0);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const uint32_t t = e0 + e;
+            if (t < tiles) {
+                const uint32_t c = fits ? cnt[e] + (t == 0u ? zero : 0u) : 0u;
+                tile_ranges[2 * t + 0] = c ? (int32_t)(t == 0u ? 0u : st[e]) : 0;
+                tile_ranges[2 * t + 1] = c ? (int32_t)st[e + 1] : 0;
+                tbase[t] = st[e];
+            }
+        }
+    }
+    if (tid == 0) {
+        tbase[tiles] = (uint32_t)pairs;
+        snap[2] = fits ? 1u : 0u;
+        const unsigned long long host_total = bad ? ~0ull : pairs;
+        total[0] = bad ? 0ull : pairs;
+        total[1] = host_total;
+        if (total_mapped) __hip_atomic_store(total_mapped, host_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// A WAVE per (group of the depth order, block of 8 x 8 tiles): lane = tile, the next free slot of the lane's tile lives in a
+// register, and the wave walks - in depth order - the records of the group whose rectangle touches its block; each one
+// is ONE masked store: the lanes inside the rectangle write the Gaussian's index to their tile's slot and advance.
+// Stable by construction (one wave per tile, records in order): no atomics, no ranking, no LDS round trip in the loop, and
+// tens of thousands of independent waves that hide each other's latencies.
+// A workgroup is up to eight horizontally adjacent blocks.  Its waves first share out a pre-filter - each takes a slice of the
+// group's records straight from memory and lists in LDS, in order, the ones that touch the workgroup's 8-row, <= 64-column
+// window (one in twelve at 1080p), with their Gaussian index (fetched for those only) - and every wave then tests only
+// the listed ones against its own block.
+constexpr int BIN_BLK = 8;                        // tile block edge: 64 tiles, one per lane
+constexpr int BIN_WG_WAVES = 8;
+constexpr int BIN_SLICE = 512;                    // records per wave and stage in the pre-filter
+constexpr int BIN_SLICE_STEPS = BIN_SLICE / CUGS_WAVE;
+__global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
+    uint32_t n, uint32_t group, uint32_t nbx, uint32_t nby, uint32_t gxs, const uint32_t* __restrict__ order,
+    const uint32_t* __restrict__ prect, uint32_t ntx, uint32_t nty, const uint32_t* __restrict__ table,
+    const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ snap, uint32_t* __restrict__ out, uint32_t ablate) {
+    __shared__ uint2 s_cand[BIN_WG_WAVES][BIN_SLICE];                 // {packed rectangle, Gaussian} of the listed records
+    __shared__ uint32_t s_cnt[BIN_WG_WAVES];
+    if (snap[2] == 0u) return;                                        // invalid or too small a buffer: k_bin_starts
+#ifdef CUGS_DEV
+    const uint32_t abl = ablate;                                      // tools/ablate_bin.py
+#else
+    constexpr uint32_t abl = 0u;
+#endif
+    const uint32_t nt = blockDim.x, nw = nt >> 6, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+    const uint32_t per_group = nby * gxs;
+    const uint32_t blk = blockIdx.x / per_group, rem = blockIdx.x - blk * per_group;
+    const uint32_t by = rem / gxs, gx = rem - by * gxs;
+    const uint32_t zero = snap[0];
+    if (blk == 0u)                                                    // the Q12 slots: (tile 0, Gaussian 0) pairs
+        for (uint32_t k = rem * nt + tid; k < zero; k += per_group * nt) out[k] = 0u;
+    const uint32_t bx = gx * nw + wid;
+    const bool active = bx < nbx;
+    const uint32_t tx = bx * BIN_BLK + (lane & 7u), ty = by * BIN_BLK + (lane >> 3);      // this lane's tile
+    uint32_t pos = 0u;                                                // BYTE offset of the tile's next slot
+    if (active && tx < ntx && ty < nty) {
+        const uint32_t t = ty * ntx + tx;
+        pos = (tbase[t] + table[(size_t)blk * (ntx * nty) + t]) * 4u;
+    }
+    // the workgroup's window, in tiles
+    const uint32_t win_y0 = by * BIN_BLK, win_y1 = win_y0 + BIN_BLK;
+    const uint32_t win_x0 = gx * nw * BIN_BLK, win_x1 = win_x0 + nw * BIN_BLK;
+    const uint32_t blk_x0 = bx * BIN_BLK, blk_x1 = blk_x0 + BIN_BLK;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    char* const outb = reinterpret_cast<char*>(out);
+    const uint32_t base = blk * group;
+    const uint32_t end = min(n, base + group);                        // base < end: the grid covers ceil(n / group) groups
+    const uint32_t stage = nw * BIN_SLICE;
+    for (uint32_t c0 = base; c0 < end; c0 += stage) {
+        __syncthreads();                                              // every wave is done with the last stage's lists
+        {   // pre-filter: this wave's slice against the workgroup's window (a record without a rectangle has bit 31 set)
+            const uint32_t s_begin = c0 + wid * BIN_SLICE;
+            uint32_t pr[BIN_SLICE_STEPS], gq[BIN_SLICE_STEPS];
+            bool ov[BIN_SLICE_STEPS];
+#pragma unroll
+            for (int u = 0; u < BIN_SLICE_STEPS; ++u) {               // all loads first (clamped addresses, no branches):
+                const uint32_t i = s_begin + (uint32_t)u * CUGS_WAVE + lane;      // ONE memory round trip per stage
+                pr[u] = prect[min(i, end - 1u)];
+                gq[u] = order[min(i, end - 1u)];
+                if (i >= end) pr[u] = 0x80000000u;
+            }
+#pragma unroll
+            for (int u = 0; u < BIN_SLICE_STEPS; ++u) {
+                const uint32_t x0 = pr[u] & 127u, y0 = (pr[u] >> 7) & 127u, w = (pr[u] >> 14) & 127u, h = (pr[u] >> 21) & 127u;
+                ov[u] = (int32_t)pr[u] >= 0 && y0 < win_y1 && y0 + h > win_y0 && x0 < win_x1 && x0 + w > win_x0;
+            }
+            uint32_t found = 0u;
+#pragma unroll
+            for (int u = 0; u < BIN_SLICE_STEPS; ++u) {
+                const unsigned long long m = __ballot(ov[u]);
+                if (ov[u]) s_cand[wid][found + (uint32_t)__popcll(m & lt_mask)] = make_uint2(pr[u], gq[u]);
+                found += (uint32_t)__popcll(m);
+            }
+            if (lane == 0u) s_cnt[wid] = found;
+        }
+        __syncthreads();
+        if (!active) continue;
+        for (uint32_t w2 = 0; w2 < nw; ++w2) {                        // the slices' lists one after the other: depth order
+            const uint32_t c = s_cnt[w2];
+            for (uint32_t k0 = 0; k0 < c; k0 += CUGS_WAVE) {
+                uint2 rec = make_uint2(0x80000000u, 0u);
+                if (k0 + lane < c) rec = s_cand[w2][k0 + lane];
+                const uint32_t x0v = rec.x & 127u, wv = (rec.x >> 14) & 127u;
+                unsigned long long m = __ballot((int32_t)rec.x >= 0 && x0v < blk_x1 && x0v + wv > blk_x0);
+                if (abl & 8u) m = 0ull;
+                while (m != 0ull) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const uint32_t prl = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, l);
+                    const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)rec.y, l);
+                    const uint32_t x0 = prl & 127u, y0 = (prl >> 7) & 127u, w = (prl >> 14) & 127u, h = (prl >> 21) & 127u;
+                    const bool in = ((tx - x0) < w) & ((ty - y0) < h);     // unsigned: inside the rectangle
+                    if (in) {
+                        if (!(abl & 1u)) *reinterpret_cast<uint32_t*>(outb + pos) = g;
+                        pos += 4u;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// SortingOutput::gaussian_keys_sorted for the direct route (only when the caller asks for the keys): the tile of pair i
+// is the last tile whose list starts at or before i.
+__global__ __launch_bounds__(CUGS_BLOCK) void k_bin_keys(uint32_t pairs_or_cap, const unsigned long long* __restrict__ dev_count,
+                                                         uint32_t tiles, const uint32_t* __restrict__ tbase,
+                                                         const uint32_t* __restrict__ zero_snap,
+                                                         const int32_t* __restrict__ pidx, const float* __restrict__ depths,
+                                                         uint64_t* __restrict__ keys_sorted) {
+    const uint32_t total = live_count(pairs_or_cap, dev_count);
+    const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
+    if (i >= total) return;
+    if (i < *zero_snap) { keys_sorted[i] = 0ull; return; }            // Q12 pairs: key 0
+    uint32_t lo = 0u, hi = tiles;                                     // largest t in [0, tiles) with tbase[t] <= i (tbase[0] = Z <= i)
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tbase[mid] <= i) lo = mid; else hi = mid;
+    }
+    keys_sorted[i] = ((uint64_t)lo << 32) | (uint64_t)__float_as_uint(depths[pidx[i]]);
+}
+
 #ifdef CUGS_DEV
 // ---- development build only (libcugs_hip_dev.so): ranking by one LDS atomic-with-return per item -------------
 // Measured 7 % faster than the ballot ranking (sort 0.250 -> 0.232 ms at config 3), but it relies on an ordering
@@ -1001,6 +1368,12 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
     return 0;
 }
 
+#ifdef CUGS_DEV
+inline uint32_t bin_ablate() { const char* e = std::getenv("CUGS_BIN_ABLATE"); return e ? (uint32_t)std::atoi(e) : 0u; }
+#else
+constexpr uint32_t bin_ablate() { return 0u; }
+#endif
+
 // Column-ordered pair emission: (row << 8 | column) must fit the 16-bit key.  Measured on MI355X, 1 M Gaussians at
 // 1080p, whole sort (tools/sort_routes.py): 8.4 pairs per Gaussian 0.249 ms against 0.218 ms for emission in depth
 // order + two radix passes; 14.8: 0.273 / 0.294; 23.5: 0.331 / 0.423; 45.2: 0.513 / 0.706 - it costs more per
@@ -1026,9 +1399,36 @@ template <typename K>
 int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t up, const float* means_2d,
                      const float* depths, const int32_t* radii, const int32_t* tiles_touched, int width, int height,
                      int ntx, int nty, uint64_t* keys_sorted, int32_t* values_sorted, int32_t* tile_ranges,
-                     const unsigned long long* dev_count, hipStream_t st) {
+                     const unsigned long long* dev_count, hipStream_t st, bool direct,
+                     unsigned long long* total_mapped = nullptr) {
     const int tiles = ntx * nty;
     const uint32_t* order = ws.dval[1];                 // left there by cugs_sort_count_pairs
+    if (direct) {
+        // (3b) every pair straight to its place (queue_count(direct) left the prefixes, the tile starts and the depth-ordered
+        // packed rectangles in the N-level workspace); the pair-level workspace is not used
+        uint32_t* const snap = reinterpret_cast<uint32_t*>(ws.total) + 10;   // [0] Q12 pairs, [1] range flag, [2] "the pairs fit"
+        const uint32_t* zsnap = snap;
+        hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(BIN_NT), 0, st, (uint32_t)tiles, up, dev_count != nullptr, ws.bin_ttot, snap,
+                           ws.bin_tbase, ws.total, total_mapped, tile_ranges);
+        CUGS_LAUNCH_CHECK();
+        if (up > 0u) {
+            // blocks of 8 x 8 tiles, one per wave; workgroups of up to 8 horizontally adjacent blocks, evenly filled
+            // (15 block columns: 8 + 7)
+            const uint32_t nbx = ((uint32_t)ntx + BIN_BLK - 1u) / BIN_BLK, nby = ((uint32_t)nty + BIN_BLK - 1u) / BIN_BLK;
+            const uint32_t gxs = (nbx + BIN_WG_WAVES - 1u) / BIN_WG_WAVES;
+            uint32_t waves = (nbx + gxs - 1u) / gxs;
+            hipLaunchKernelGGL(k_bin_scatter, dim3(bin_rows(un) * nby * gxs), dim3(waves * CUGS_WAVE), 0, st, un, bin_group(), nbx, nby, gxs,
+                               order, static_cast<const uint32_t*>(ws.prect[1]), (uint32_t)ntx, (uint32_t)nty, ws.bin_table,
+                               ws.bin_tbase, zsnap, reinterpret_cast<uint32_t*>(values_sorted), bin_ablate());
+            CUGS_LAUNCH_CHECK();
+        }
+        if (keys_sorted) {
+            hipLaunchKernelGGL(k_bin_keys, dim3(nblocks_for(up, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, up, dev_count, (uint32_t)tiles,
+                               ws.bin_tbase, zsnap, values_sorted, depths, keys_sorted);
+            CUGS_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
     uint32_t* ctl = reinterpret_cast<uint32_t*>(ws.total) + 4;        // [0] Q12 counter, [1] its snapshot
     const int bits = tile_bits(tiles);
@@ -1091,10 +1491,13 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
 // outside that range the totals say so (k_scan_blocksums) and the caller runs this again with three_pass = false.
 int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const float* depths, const int32_t* radii,
                 const int32_t* tiles_touched, int width, int height, int ntx, int nty, hipStream_t st,
-                unsigned long long* total_mapped = nullptr, bool three_pass = true, bool prekeyed = false) {
+                unsigned long long* total_mapped = nullptr, bool three_pass = true, bool prekeyed = false,
+                bool direct = false) {
     uint32_t* range_flag = reinterpret_cast<uint32_t*>(ws.total) + 6;
+    uint32_t* const q12 = reinterpret_cast<uint32_t*>(ws.total) + 4;   // [0] Q12 counter, [1] its snapshot
     int rc;
     bool riding = false;
+    if (direct && !(three_pass && prekeyed && bin_route(ntx, nty))) return CUGS_EINVAL;
     if (three_pass) {
         // (1) stable sort of the Gaussians by depth: keys -> dkey[0], three passes [0] -> [1] -> [0] -> [1]
         // prekeyed: cugs_project_forward_keyed has left dkey[0], rect[0] and the range flag in this workspace already
@@ -1116,7 +1519,8 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
         uint32_t* const sup0 = ws.sup, *const sup1 = ws.sup + used, *const sup2 = ws.sup + 2 * (size_t)used;
         if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, sup0, ws.tot, ws.dkey[1], ws.dval[1], nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
         if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, sup1, ws.tot, ws.dkey[0], ws.dval[0], nullptr, st, riding ? pr[1] : nullptr, pr[0]))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, sup2, ws.tot, ws.dkey[1], ws.dval[1], nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
+        // direct: the last pass's histogram kernel also arms the Q12 counter k_bin_count adds to
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, sup2, ws.tot, ws.dkey[1], ws.dval[1], direct ? q12 : nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
     } else {
         // (1) the general route: four passes of 8 bits on the raw depth bits (positive floats order as unsigned ints)
         hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
@@ -1130,6 +1534,20 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
         if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[1], ws.dval[1], un, nullptr, 16, 8, ws.hist, sp[2], ws.tot, ws.dkey[0], ws.dval[0], nullptr, st))) return rc;
         if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN>(ws.dkey[0], ws.dval[0], un, nullptr, 24, 8, ws.hist, sp[3], ws.tot, ws.dkey[1], ws.dval[1], nullptr, st))) return rc;
     }
+    if (direct) {
+        // (2)-(3a) direct binning: pairs per (workgroup of the depth order, tile), their prefixes, tile starts, the total
+        // (the totals are published by the scatter: sort_pairs_typed(direct), which the caller launches in any case)
+        const uint32_t tiles = (uint32_t)(ntx * nty), rows = bin_rows(un);
+        uint32_t* const snap = reinterpret_cast<uint32_t*>(ws.total) + 10;   // [0] Q12 pairs, [1] depth range flag
+        hipLaunchKernelGGL(k_bin_count, dim3(rows), dim3(BIN_NT), 0, st, un, bin_group(), ws.dval[1], ws.rect[0],
+                           riding ? static_cast<const uint32_t*>(ws.prect[1]) : static_cast<const uint32_t*>(nullptr),
+                           ws.prect[1], (uint32_t)ntx, (uint32_t)nty, ws.bin_table, q12);
+        CUGS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bin_scan, dim3((tiles + CUGS_WAVE - 1) / CUGS_WAVE), dim3(BIN_NT), 0, st, rows, tiles, ws.bin_table,
+                           ws.bin_ttot, q12, range_flag, snap);
+        CUGS_LAUNCH_CHECK();
+        return 0;
+    }
     // (2a) pair counts per 256-Gaussian block in depth order, their scan, and the grand total
     const uint32_t nfill = nblocks_for(un, FILL_CHUNK);
     hipLaunchKernelGGL(k_fill_blocksums, dim3(nfill), dim3(CUGS_BLOCK), 0, st, un, ws.dval[1], ws.rect[0], ws.rect[1],
@@ -1140,6 +1558,13 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
     CUGS_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef CUGS_DEV
+std::atomic<int> g_direct_route{1};               // development build: 0 = the radix route on every view (A/B measurements)
+inline bool direct_route_enabled() { return g_direct_route.load(std::memory_order_relaxed) != 0; }
+#else
+constexpr bool direct_route_enabled() { return true; }
+#endif
 
 template <typename... A>
 int sort_pairs_dispatch(int tiles, A... args) {
@@ -1274,7 +1699,7 @@ extern "C" int cugs_sort_pairs(int64_t n, int64_t total_pairs, const float* mean
     // (2b) pairs in depth order; (3) stable sort by tile id, last pass landing in values_sorted; (4) ranges
     return sort_pairs_dispatch(tiles, ws, wp, (uint32_t)n, (uint32_t)total_pairs, means_2d, depths, radii, tiles_touched,
                                width, height, ntx, nty, keys_sorted, values_sorted, tile_ranges,
-                               static_cast<const unsigned long long*>(nullptr), st);
+                               static_cast<const unsigned long long*>(nullptr), st, false);
 }
 
 // The whole sort without a host round trip: the caller PREDICTS the pair count (`capacity`, e.g. the last
@@ -1317,9 +1742,24 @@ int sort_pairs_predicted_impl(int64_t n, int64_t capacity, const float* means_2d
         else
             (void)hipGetLastError();                              // an unregistered pointer is not an error here
     }
+    // the projection's own records on an image of up to ~10 000 tiles: every pair is written once, by a counting sort
+    // over the tiles (k_bin_*), instead of emitted and carried through two radix passes
+    const bool direct = prekeyed && !wide && bin_route(ntx, nty) && bin_route_n(n) && direct_route_enabled();
     int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st, mapped, !wide,
-                         prekeyed && !wide);
+                         prekeyed && !wide, direct);
     if (rc) return rc;
+    if (direct) {
+        // the scatter publishes the totals (and, with capacity 0, only does that and clears the ranges)
+        if (capacity > 0 && !values_sorted) return CUGS_EINVAL;
+        SortWsP none{};
+        rc = sort_pairs_dispatch(tiles, ws, none, (uint32_t)n, (uint32_t)capacity, means_2d, depths, radii, tiles_touched,
+                                 width, height, ntx, nty, capacity > 0 ? keys_sorted : static_cast<uint64_t*>(nullptr),
+                                 values_sorted, tile_ranges, static_cast<const unsigned long long*>(ws.total), st, true, mapped);
+        if (rc) return rc;
+        if (!mapped)
+            CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        return 0;
+    }
     if (!mapped)
         CUGS_RETURN_IF_HIP(hipMemcpyAsync(total_pairs_host, ws.total + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     if (capacity == 0) {                                          // valid iff the total turns out to be 0
@@ -1331,7 +1771,7 @@ int sort_pairs_predicted_impl(int64_t n, int64_t capacity, const float* means_2d
     if (pair_workspace_bytes < wp.bytes) return CUGS_EWORKSPACE;
     return sort_pairs_dispatch(tiles, ws, wp, (uint32_t)n, (uint32_t)capacity, means_2d, depths, radii, tiles_touched,
                                width, height, ntx, nty, keys_sorted, values_sorted, tile_ranges,
-                               static_cast<const unsigned long long*>(ws.total), st);
+                               static_cast<const unsigned long long*>(ws.total), st, false);
 }
 }  // namespace
 
@@ -1372,6 +1812,11 @@ extern "C" int cugs_sort_pairs_predicted_wide(int64_t n, int64_t capacity, const
 }
 
 #ifdef CUGS_DEV
+// Development build only: 0 = never take the direct-binning route, 1 = take it where it applies; returns the setting.
+extern "C" int cugsdbg_sort_direct_route(int on) {
+    if (on == 0 || on == 1) g_direct_route.store(on, std::memory_order_relaxed);
+    return g_direct_route.load(std::memory_order_relaxed);
+}
 // Development build only: pairs per Gaussian from which the column-ordered emission is used (0: always).
 extern "C" int cugsdbg_sort_column_ratio(int ratio) {
     if (ratio >= 0) g_col_min_ratio.store(ratio, std::memory_order_relaxed);

@@ -240,6 +240,69 @@ def test_render_recovers_from_a_wrong_pair_prediction(pkg, orc, dev):
     assert small[4].total_pairs == small[5]["total_pairs"]
 
 
+@pytest.mark.parametrize("n,w,h,mu_s,ties", [
+    (4000, 128, 96, -2.5, True),        # every depth identical (stability across workgroups and waves) + quirk Q12 zero pairs
+    (300, 640, 360, 0.5, False),        # screen-filling splats: rectangles over 16 tiles tall (several owned rows per wave)
+    (30000, 1600, 1063, -4.2, False),   # config 4's image: 100 x 67 tiles
+    (5000, 2032, 2032, -3.0, False),    # 127 x 127 tiles: packable rectangles, but over the direct route's tile limit
+    (3000, 3840, 2160, -3.5, False),    # 4K: neither packable nor direct
+])
+def test_render_sort_by_direct_binning(pkg, orc, dev, n, w, h, mu_s, ties):
+    """render()'s second and later frames on a stream sort through cugs_sort_pairs_predicted_keyed, which - on images of
+    up to ~10 000 tiles - bins every pair straight into its tile's list (k_bin_count / k_bin_scan / k_bin_scatter)
+    instead of carrying the pairs through two radix passes.  Same permutation, bit for bit: the oracle's order
+    (ascending index among equal depths), the Q12 zero pairs at the head of tile 0, {0,0} for untouched tiles; and a
+    frame whose prediction was too small (the first after a ten times smaller scene) is recovered as before."""
+    R = pkg.rasterizer
+    arrays, cam = _scene(pkg, n, w, h, 0, seed=n + w, mu_s=mu_s)
+    if ties:
+        arrays["positions"][:, 2] = np.float32(4.0)
+    K = cam.intrinsics
+    ref = orc.render(arrays, cam.rotation, cam.translation, K.fx, K.fy, K.cx, K.cy, w, h, active_degree=0,
+                     threads=orc.host_threads())
+    model = pkg.scene.to_model(arrays, dev)
+    settings = pkg.RenderSettings(active_sh_degree=0)
+    key = R._skey(torch.device(dev))
+    for attempt, forced in enumerate((None, None, 100, None)):          # exact sort, predicted, predicted miss, predicted
+        if forced is not None:
+            R._last_pairs[key] = forced
+            R._held_capacity.pop(key, None)
+        out = pkg.render(model, cam, settings)
+        assert out.total_pairs == ref["total_pairs"], attempt
+        assert np.array_equal(np_(out.gaussian_indices), ref["values"]), attempt
+        assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"]), attempt
+        assert np.array_equal(np_(out.n_contrib), ref["n_contrib"]), attempt
+    if ties:
+        nzero = int((ref["keys"] == 0).sum())
+        assert nzero > 0 and not np_(out.gaussian_indices)[:nzero].any()
+    # the keys of the reference's SortingOutput, rebuilt from the tile starts on this route
+    keyed = R.project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, cam, 0,
+                                key_sort=True)
+    pend = R.sort_gaussians_predicted(keyed.means_2d, keyed.depths, keyed.radii, keyed.tiles_touched, w, h,
+                                      want_keys=True, keyed_workspace=keyed.sort_workspace)
+    srt, valid = pend.finish()
+    assert valid and np.array_equal(np_(srt.gaussian_keys_sorted).view(np.uint64), ref["keys"])
+    assert np.array_equal(np_(srt.gaussian_values_sorted), ref["values"])
+
+
+def test_sort_routes_agree_in_the_development_build(pkg, dev):
+    """The development library can switch the direct-binning route off (cugsdbg_sort_direct_route): a sequence of
+    scenes of changing size on one stream - predictions from the previous scene: hits and misses - must give the same
+    pairs, ranges and image with the route on and off (tools/direct_route_check.py; the shipped library has no switch)."""
+    import ctypes as C
+    import subprocess
+    import sys
+    assert not hasattr(C.CDLL(pkg.LIB_PATH), "cugsdbg_sort_direct_route")
+    dev_lib = os.path.join(os.path.dirname(pkg.LIB_PATH), "libcugs_hip_dev.so")
+    if not os.path.exists(dev_lib):
+        pytest.skip("development library not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "direct_route_check.py")], capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, CUGS_HIP_LIBRARY=dev_lib))
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-2000:])
+    assert "bad 0" in res.stdout and res.stdout.count(" same") >= 12
+
+
 def test_sort_equal_depth_ties_keep_index_order(pkg, orc, dev):
     """CUB's stability contract: equal (tile, depth) keys stay in ascending Gaussian index."""
     w, h, n = 128, 96, 4000
