@@ -69,6 +69,8 @@ struct SortWsN {
     uint32_t* colscan;           // ... and scanned along each column's row
     uint32_t* bin_table;         // direct binning: [rows][tiles] pairs per (workgroup of the depth order, tile), then their prefix
     uint32_t* bin_ttot;          // [tiles] pairs per tile
+    uint32_t* bin_tpre;          // [tiles] pairs of the earlier tiles of the tile's 64-tile chunk
+    uint32_t* bin_csum;          // [chunks] pairs per 64-tile chunk
     uint32_t* bin_tbase;         // [tiles + 1] first real pair of each tile; [tiles] = pair total
     size_t bytes;
 };
@@ -112,7 +114,6 @@ inline uint32_t sup_used(uint32_t nblk, int rdx, uint32_t grp) { return (uint32_
 // Direct binning (k_bin_count / k_bin_scan / k_bin_scatter further down): table geometry, needed by the workspace carving.
 constexpr int BIN_TILES_CAP = 10240;              // tiles of the image (k_bin_count's LDS row)
 constexpr uint32_t BIN_GROUP = 4096u, BIN_ROWS_MAX = 512u;
-constexpr int BIN_TTOT_PAD = 12288;                // dwords of the per-tile totals: twelve per thread of k_bin_starts
 // Gaussians per table row (and per workgroup of k_bin_count): measured best of 2048 ... 16384 at 1 M Gaussians.  The route is
 // taken for up to BIN_ROWS_MAX rows = 2 M Gaussians: at 6 M (40 M pairs) it ties with the radix passes (0.83 ms both,
 // profiles/r03_s_direct_binning.log), which stay in charge there.
@@ -151,8 +152,10 @@ SortWsN carve_n(void* base, int64_t n) {
     w.colhist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
     w.colscan = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
     w.bin_table = c.take<uint32_t>((size_t)bin_table_rows(n) * BIN_TILES_CAP);
-    w.bin_ttot = c.take<uint32_t>(BIN_TTOT_PAD);
-    w.bin_tbase = c.take<uint32_t>(BIN_TTOT_PAD + 4);
+    w.bin_ttot = c.take<uint32_t>(BIN_TILES_CAP);
+    w.bin_tpre = c.take<uint32_t>(BIN_TILES_CAP);
+    w.bin_csum = c.take<uint32_t>(BIN_TILES_CAP / 64 + 4);
+    w.bin_tbase = c.take<uint32_t>(BIN_TILES_CAP + 1);
     w.bytes = c.off;
     return w;
 }
@@ -921,14 +924,14 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_tile_ranges(uint32_t pairs_or_ca
 // Direct binning (round 3): steps (2)-(4) as ONE counting sort by tile id, for views of up to 2 M Gaussians on images of up
 // to BIN_T_MAX tiles whose per-Gaussian records are the projection's packed rectangles (render()'s route).  The two
 // radix passes over the pairs (emit tile id + index, histogram, scatter, histogram, scatter, range detection: eight
-// launches, every pair written three times and read four) become four launches that write every pair ONCE:
+// launches, every pair written three times and read four) become three launches that write every pair ONCE:
 //   k_bin_count    a workgroup takes a GROUP of 4096 consecutive Gaussians of the depth order and counts, in LDS, how
 //                  many of them cover each tile: row b of the table [groups][tiles];
 //   k_bin_scan     per tile, the exclusive prefix of its column of the table (= where group b's first pair of the tile
-//                  goes inside the tile's list) and the tile's total;
-//   k_bin_starts   the tile totals scanned into tile starts; publishes the pair total and the tile ranges;
-//   k_bin_scatter  a wave per (group, block of 8 x 8 tiles) walks the group's records in depth order and writes each
-//                  pair's Gaussian index straight to  tile start + prefix + pairs of this group written so far.
+//                  goes inside the tile's list), the tile's total, and the totals of 64-tile chunks;
+//   k_bin_scatter  a wave per (group, block of 8 x 8 tiles) scans the chunk totals into its tiles' starts, walks the
+//                  group's records in depth order and writes each pair's Gaussian index straight to
+//                  tile start + prefix + pairs of this group written so far; group 0's waves publish the ranges.
 // What makes the last kernel a STABLE sort (ties in depth order, bit for bit what the radix passes give): every
 // (group, tile) has exactly one writer, a lane that visits the records in order.
 // Measured, whole sort, same box (tools/ablate_bin.py, profiles/r03_s_direct_binning.log): 1 M Gaussians / 8.4 M pairs
@@ -1021,9 +1024,11 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_count(uint32_t n, uint32_t group
 // k_bin_count has finished adding to (snap[0]; the counter is re-armed) and the depth range flag (snap[1]; re-armed).
 // No grid-wide step here: a workgroup that waits for the others' totals must first make its own visible across the
 // XCDs' L2s (a release fence = an L2 write-back with 8 MB of freshly written table in it: this kernel took 52 us that
-// way); the scatter's workgroups each scan the 8 K tile totals themselves instead (1-2 us, all at once).
+// way).  Each workgroup leaves the prefix of its 64 tiles' totals and their sum (a chunk) instead; the scatter's waves
+// finish the scan over the <= 160 chunk sums themselves.
 __global__ __launch_bounds__(BIN_NT) void k_bin_scan(uint32_t rows, uint32_t tiles, uint32_t* __restrict__ table,
-                                                     uint32_t* __restrict__ ttot, uint32_t* __restrict__ q12,
+                                                     uint32_t* __restrict__ ttot, uint32_t* __restrict__ tpre,
+                                                     uint32_t* __restrict__ csum, uint32_t* __restrict__ q12,
                                                      uint32_t* __restrict__ range_flag, uint32_t* __restrict__ snap) {
     __shared__ uint32_t s_seg[BIN_WAVES][CUGS_WAVE];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1056,86 +1061,12 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scan(uint32_t rows, uint32_t til
             table[(size_t)r * tiles + t] = run;
             run += v;
         }
-        if (seg == 0u) ttot[t] = tot;
     }
-}
-
-// One workgroup: the tile totals scanned into tile starts - tbase[t] = where the first REAL pair of tile t goes (tile 0's
-// list begins with the Q12 zero pairs, see k_fill_pairs), tbase[tiles] = the pair total - plus everything
-// k_scan_blocksums publishes on the radix route (the totals, the host's copy) and the tile ranges.
-// predicted: pairs_or_cap is the capacity of the index buffer (else the exact pair count).  When the pairs do not fit
-// (or the depth order is invalid: a key outside the three-pass range) the result is declared invalid through the total,
-// as on the radix route; the scatter then writes nothing (snap[2] = 0) and EVERY range is {0,0}, so that the blend
-// queued behind it does nothing instead of walking an unwritten index buffer.
-__global__ __launch_bounds__(BIN_NT) void k_bin_starts(uint32_t tiles, uint32_t pairs_or_cap, bool predicted,
-                                                       const uint32_t* __restrict__ ttot, uint32_t* __restrict__ snap,
-                                                       uint32_t* __restrict__ tbase, unsigned long long* __restrict__ total,
-                                                       unsigned long long* __restrict__ total_mapped,
-                                                       int32_t* __restrict__ tile_ranges) {
-    __shared__ uint32_t s_tmp[BIN_WAVES];
-    __shared__ unsigned long long s_sum[BIN_WAVES];
-    const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
-    // twelve consecutive tiles per thread, fetched as three 16-byte loads (ttot has BIN_TTOT_PAD dwords; entries beyond
-    // `tiles` are whatever the workspace held and are masked)
-    constexpr int PER = BIN_TTOT_PAD / BIN_NT;
-    static_assert(PER == 12 && PER * BIN_NT >= BIN_T_MAX + 1, "three uint4 per thread cover every tile");
-    const uint32_t e0 = tid * PER;
-    uint32_t cnt[PER], part = 0u;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(ttot + e0);
-        const uint4 q0 = src[0], q1 = src[1], q2 = src[2];
-        const uint32_t raw[PER] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-#pragma unroll
-        for (int e = 0; e < PER; ++e) { cnt[e] = (e0 + e < tiles) ? raw[e] : 0u; part += cnt[e]; }
-    }
-    const uint32_t zero = snap[0];
-    const bool bad = snap[1] != 0u;
-    uint32_t run = zero + block_exclusive_scan<BIN_WAVES>(part, s_tmp, nullptr);
-    unsigned long long wide = part;                                   // the grand total in 64 bits (int32 overflow is the host's check)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wide += __shfl_down(wide, d);
-    if (lane == 0u) s_sum[wid] = wide;
-    __syncthreads();
-    unsigned long long pairs = zero;
-#pragma unroll
-    for (int w2 = 0; w2 < BIN_WAVES; ++w2) pairs += s_sum[w2];
-    const bool fits = !bad && (!predicted || pairs <= (unsigned long long)pairs_or_cap);
-    uint32_t st[PER + 1];
-#pragma unroll
-    for (int e = 0; e < PER; ++e) { st[e] = run; run += cnt[e]; }
-    st[PER] = run;
-    if (e0 + PER <= tiles) {                                          // whole 16-byte stores
-        uint4* tb = reinterpret_cast<uint4*>(tbase + e0);
-        tb[0] = make_uint4(st[0], st[1], st[2], st[3]);
-        tb[1] = make_uint4(st[4], st[5], st[6], st[7]);
-        tb[2] = make_uint4(st[8], st[9], st[10], st[11]);
-        int4* tr = reinterpret_cast<int4*>(tile_ranges + 2 * (size_t)e0);
-#pragma unroll
-        for (int e = 0; e < PER; e += 2) {
-            const uint32_t t = e0 + e;
-            const uint32_t ca = fits ? cnt[e] + (t == 0u ? zero : 0u) : 0u, cb = fits ? cnt[e + 1] : 0u;   // {0,0}: sorting.cu:216
-            tr[e / 2] = make_int4(ca ? (int32_t)(t == 0u ? 0u : st[e]) : 0, ca ? (int32_t)st[e + 1] : 0,
-                                  cb ? (int32_t)st[e + 1] : 0, cb ? (int32_t)st[e + 2] : 0);
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const uint32_t t = e0 + e;
-            if (t < tiles) {
-                const uint32_t c = fits ? cnt[e] + (t == 0u ? zero : 0u) : 0u;
-                tile_ranges[2 * t + 0] = c ? (int32_t)(t == 0u ? 0u : st[e]) : 0;
-                tile_ranges[2 * t + 1] = c ? (int32_t)st[e + 1] : 0;
-                tbase[t] = st[e];
-            }
-        }
-    }
-    if (tid == 0) {
-        tbase[tiles] = (uint32_t)pairs;
-        snap[2] = fits ? 1u : 0u;
-        const unsigned long long host_total = bad ? ~0ull : pairs;
-        total[0] = bad ? 0ull : pairs;
-        total[1] = host_total;
-        if (total_mapped) __hip_atomic_store(total_mapped, host_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (seg == 0u) {                                                  // this workgroup's 64 tiles (a CHUNK): totals, their prefix, their sum
+        const uint32_t v = t < tiles ? tot : 0u;
+        const uint32_t inc = wave_inclusive_scan(v);
+        if (t < tiles) { ttot[t] = v; tpre[t] = inc - v; }
+        if (tl == 63u) csum[blockIdx.x] = inc;
     }
 }
 
@@ -1153,12 +1084,14 @@ constexpr int BIN_WG_WAVES = 8;
 constexpr int BIN_SLICE = 512;                    // records per wave and stage in the pre-filter
 constexpr int BIN_SLICE_STEPS = BIN_SLICE / CUGS_WAVE;
 __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
-    uint32_t n, uint32_t group, uint32_t nbx, uint32_t nby, uint32_t gxs, const uint32_t* __restrict__ order,
-    const uint32_t* __restrict__ prect, uint32_t ntx, uint32_t nty, const uint32_t* __restrict__ table,
-    const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ snap, uint32_t* __restrict__ out, uint32_t ablate) {
+    uint32_t n, uint32_t group, uint32_t nbx, uint32_t nby, uint32_t gxs, uint32_t pairs_or_cap, bool predicted,
+    const uint32_t* __restrict__ order, const uint32_t* __restrict__ prect, uint32_t ntx, uint32_t nty,
+    const uint32_t* __restrict__ table, const uint32_t* __restrict__ ttot, const uint32_t* __restrict__ tpre,
+    const uint32_t* __restrict__ csum, const uint32_t* __restrict__ snap, uint32_t* __restrict__ tbase,
+    unsigned long long* __restrict__ total, unsigned long long* __restrict__ total_mapped, uint32_t* __restrict__ out,
+    int32_t* __restrict__ tile_ranges, uint32_t ablate) {
     __shared__ uint2 s_cand[BIN_WG_WAVES][BIN_SLICE];                 // {packed rectangle, Gaussian} of the listed records
     __shared__ uint32_t s_cnt[BIN_WG_WAVES];
-    if (snap[2] == 0u) return;                                        // invalid or too small a buffer: k_bin_starts
 #ifdef CUGS_DEV
     const uint32_t abl = ablate;                                      // tools/ablate_bin.py
 #else
@@ -1168,17 +1101,72 @@ __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
     const uint32_t per_group = nby * gxs;
     const uint32_t blk = blockIdx.x / per_group, rem = blockIdx.x - blk * per_group;
     const uint32_t by = rem / gxs, gx = rem - by * gxs;
-    const uint32_t zero = snap[0];
-    if (blk == 0u)                                                    // the Q12 slots: (tile 0, Gaussian 0) pairs
-        for (uint32_t k = rem * nt + tid; k < zero; k += per_group * nt) out[k] = 0u;
+    const uint32_t zero = snap[0];                                    // quirk Q12's (tile 0, Gaussian 0) pairs: the head of tile 0's list
+    const bool bad = snap[1] != 0u;                                   // a depth key outside the three-pass range: nothing is valid
+    const uint32_t tiles = ntx * nty;
+
+    // Tile starts, by every wave for itself (a kernel of its own for this scan cost 10 us of the frame): the totals of the
+    // 64-tile chunks (k_bin_scan's workgroups: <= 160 of them) scanned across the lanes, + the tile's prefix inside its chunk.
+    const uint32_t nch = (tiles + CUGS_WAVE - 1u) / CUGS_WAVE;
+    uint32_t cpre[3] = {0u, 0u, 0u};                                  // exclusive prefix of chunk (lane + 64 i)
+    uint32_t pairs = zero;                                            // the pair total, SATURATING at 2^32 - 1 (such a total never fits)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if ((uint32_t)i * CUGS_WAVE < nch) {                          // kernel-uniform: 128 chunks at 1080p = two scans
+            const uint32_t c = lane + (uint32_t)i * CUGS_WAVE;
+            const uint32_t v = c < nch ? csum[c] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d);
+                const uint32_t sum = inc + o;
+                if ((int)lane >= d) inc = sum < o ? 0xFFFFFFFFu : sum;
+            }
+            const uint32_t with = inc + pairs;                        // + the chunks of the earlier scans (and the Q12 pairs)
+            cpre[i] = (with < inc ? 0xFFFFFFFFu : with) - v;          // (meaningless once saturated: nothing is written then)
+            const uint32_t last = __shfl(inc, 63), tot = last + pairs;
+            pairs = tot < last ? 0xFFFFFFFFu : tot;
+        }
+    }
+    const bool fits = !bad && (!predicted || pairs <= pairs_or_cap);
+    cpre[0] -= zero; cpre[1] -= zero; cpre[2] -= zero;                // (the Q12 pairs are added to `start` below)
+
     const uint32_t bx = gx * nw + wid;
     const bool active = bx < nbx;
     const uint32_t tx = bx * BIN_BLK + (lane & 7u), ty = by * BIN_BLK + (lane >> 3);      // this lane's tile
-    uint32_t pos = 0u;                                                // BYTE offset of the tile's next slot
-    if (active && tx < ntx && ty < nty) {
-        const uint32_t t = ty * ntx + tx;
-        pos = (tbase[t] + table[(size_t)blk * (ntx * nty) + t]) * 4u;
+    const bool tile_ok = active && tx < ntx && ty < nty;
+    const uint32_t t = tile_ok ? ty * ntx + tx : 0u;
+    uint32_t start;                                                   // where the first REAL pair of the tile goes
+    {
+        const uint32_t ch = t >> 6;
+        const uint32_t p0 = __shfl(cpre[0], ch & 63u), p1 = __shfl(cpre[1], ch & 63u), p2 = __shfl(cpre[2], ch & 63u);
+        start = zero + (ch < 64u ? p0 : ch < 128u ? p1 : p2) + (tile_ok ? tpre[t] : 0u);
     }
+    uint32_t pos = tile_ok ? (start + table[(size_t)blk * tiles + t]) * 4u : 0u;           // BYTE offset of the tile's next slot
+    if (blk == 0u) {
+        // group 0's waves cover every tile once: they publish what k_scan_blocksums / k_tile_ranges publish on the radix
+        // route.  When the pairs do not fit the buffer (or the depth order is invalid) the result is declared invalid
+        // through the total, nothing is written, and EVERY range is {0,0}: the blend queued behind this kernel then does
+        // nothing instead of walking an unwritten index buffer.
+        if (tile_ok) {
+            const uint32_t c = fits ? ttot[t] + (t == 0u ? zero : 0u) : 0u;                 // {0,0} for untouched tiles (sorting.cu:216)
+            tile_ranges[2 * t + 0] = c ? (int32_t)(t == 0u ? 0u : start) : 0;
+            tile_ranges[2 * t + 1] = c ? (int32_t)(start + ttot[t]) : 0;
+            tbase[t] = start;
+        }
+        if (rem == 0u && tid == 0u) {
+            unsigned long long exact = zero;                          // in 64 bits: int32 overflow is the host's check
+            for (uint32_t c = 0; c < nch; ++c) exact += csum[c];
+            tbase[tiles] = pairs;
+            const unsigned long long host_total = bad ? ~0ull : exact;
+            total[0] = bad ? 0ull : exact;
+            total[1] = host_total;
+            if (total_mapped) __hip_atomic_store(total_mapped, host_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (!fits) return;
+    if (blk == 0u)                                                    // the Q12 slots: (tile 0, Gaussian 0) pairs
+        for (uint32_t k = rem * nt + tid; k < zero; k += per_group * nt) out[k] = 0u;
     // the workgroup's window, in tiles
     const uint32_t win_y0 = by * BIN_BLK, win_y1 = win_y0 + BIN_BLK;
     const uint32_t win_x0 = gx * nw * BIN_BLK, win_x1 = win_x0 + nw * BIN_BLK;
@@ -1249,6 +1237,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_bin_keys(uint32_t pairs_or_cap, 
                                                          const uint32_t* __restrict__ zero_snap,
                                                          const int32_t* __restrict__ pidx, const float* __restrict__ depths,
                                                          uint64_t* __restrict__ keys_sorted) {
+    if (dev_count && *dev_count > (unsigned long long)pairs_or_cap) return;   // the pairs did not fit: no indices were written
     const uint32_t total = live_count(pairs_or_cap, dev_count);
     const uint32_t i = blockIdx.x * CUGS_BLOCK + threadIdx.x;
     if (i >= total) return;
@@ -1406,22 +1395,17 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
     if (direct) {
         // (3b) every pair straight to its place (queue_count(direct) left the prefixes, the tile starts and the depth-ordered
         // packed rectangles in the N-level workspace); the pair-level workspace is not used
-        uint32_t* const snap = reinterpret_cast<uint32_t*>(ws.total) + 10;   // [0] Q12 pairs, [1] range flag, [2] "the pairs fit"
-        const uint32_t* zsnap = snap;
-        hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(BIN_NT), 0, st, (uint32_t)tiles, up, dev_count != nullptr, ws.bin_ttot, snap,
-                           ws.bin_tbase, ws.total, total_mapped, tile_ranges);
+        const uint32_t* zsnap = reinterpret_cast<const uint32_t*>(ws.total) + 10;       // [0] Q12 pairs, [1] depth range flag
+        // blocks of 8 x 8 tiles, one per wave; workgroups of up to 8 horizontally adjacent blocks, evenly filled
+        // (15 block columns: 8 + 7).  Launched for capacity 0 too: the kernel publishes the totals and the ranges.
+        const uint32_t nbx = ((uint32_t)ntx + BIN_BLK - 1u) / BIN_BLK, nby = ((uint32_t)nty + BIN_BLK - 1u) / BIN_BLK;
+        const uint32_t gxs = (nbx + BIN_WG_WAVES - 1u) / BIN_WG_WAVES;
+        const uint32_t waves = (nbx + gxs - 1u) / gxs;
+        hipLaunchKernelGGL(k_bin_scatter, dim3(bin_rows(un) * nby * gxs), dim3(waves * CUGS_WAVE), 0, st, un, bin_group(), nbx, nby, gxs,
+                           up, dev_count != nullptr, order, static_cast<const uint32_t*>(ws.prect[1]), (uint32_t)ntx, (uint32_t)nty,
+                           ws.bin_table, ws.bin_ttot, ws.bin_tpre, ws.bin_csum, zsnap, ws.bin_tbase, ws.total, total_mapped,
+                           reinterpret_cast<uint32_t*>(values_sorted), tile_ranges, bin_ablate());
         CUGS_LAUNCH_CHECK();
-        if (up > 0u) {
-            // blocks of 8 x 8 tiles, one per wave; workgroups of up to 8 horizontally adjacent blocks, evenly filled
-            // (15 block columns: 8 + 7)
-            const uint32_t nbx = ((uint32_t)ntx + BIN_BLK - 1u) / BIN_BLK, nby = ((uint32_t)nty + BIN_BLK - 1u) / BIN_BLK;
-            const uint32_t gxs = (nbx + BIN_WG_WAVES - 1u) / BIN_WG_WAVES;
-            uint32_t waves = (nbx + gxs - 1u) / gxs;
-            hipLaunchKernelGGL(k_bin_scatter, dim3(bin_rows(un) * nby * gxs), dim3(waves * CUGS_WAVE), 0, st, un, bin_group(), nbx, nby, gxs,
-                               order, static_cast<const uint32_t*>(ws.prect[1]), (uint32_t)ntx, (uint32_t)nty, ws.bin_table,
-                               ws.bin_tbase, zsnap, reinterpret_cast<uint32_t*>(values_sorted), bin_ablate());
-            CUGS_LAUNCH_CHECK();
-        }
         if (keys_sorted) {
             hipLaunchKernelGGL(k_bin_keys, dim3(nblocks_for(up, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, up, dev_count, (uint32_t)tiles,
                                ws.bin_tbase, zsnap, values_sorted, depths, keys_sorted);
@@ -1544,7 +1528,7 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
                            ws.prect[1], (uint32_t)ntx, (uint32_t)nty, ws.bin_table, q12);
         CUGS_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bin_scan, dim3((tiles + CUGS_WAVE - 1) / CUGS_WAVE), dim3(BIN_NT), 0, st, rows, tiles, ws.bin_table,
-                           ws.bin_ttot, q12, range_flag, snap);
+                           ws.bin_ttot, ws.bin_tpre, ws.bin_csum, q12, range_flag, snap);
         CUGS_LAUNCH_CHECK();
         return 0;
     }
@@ -1744,7 +1728,9 @@ int sort_pairs_predicted_impl(int64_t n, int64_t capacity, const float* means_2d
     }
     // the projection's own records on an image of up to ~10 000 tiles: every pair is written once, by a counting sort
     // over the tiles (k_bin_*), instead of emitted and carried through two radix passes
-    const bool direct = prekeyed && !wide && bin_route(ntx, nty) && bin_route_n(n) && direct_route_enabled();
+    // (capacity below 2^30: the scatter keeps 32-bit byte offsets into the index buffer)
+    const bool direct = prekeyed && !wide && bin_route(ntx, nty) && bin_route_n(n) && capacity < (int64_t(1) << 30) &&
+                        direct_route_enabled();
     int rc = queue_count(ws, (uint32_t)n, means_2d, depths, radii, tiles_touched, width, height, ntx, nty, st, mapped, !wide,
                          prekeyed && !wide, direct);
     if (rc) return rc;
