@@ -35,13 +35,25 @@ for k in sorted(set(fetch) | set(write)):
                      "hbm_bytes_corrected": round(2 * f + w)}
 # one frame = everything between two launches of the projection: total corrected bytes of all sampled launches / frames
 frames = max((len(v) for k, v in fetch.items() if "k_project_forward" in k), default=0)
+# ... of a STEADY frame: the first frame of a process sorts on the blocking route (no pair-count prediction yet) and
+# launches kernels no later frame does; only kernels seen in all frames but one count, each at its mean per launch
+# times its launches per frame
 frame_bytes = None
+first_frame_only = []
 if frames:
-    frame_bytes = round(sum(2 * sum(fetch.get(k, [])) * 1024 + sum(write.get(k, [])) * 1024 for k in set(fetch) | set(write)) / frames)
-json.dump({"frames_sampled": frames, "frame_hbm_bytes_corrected": frame_bytes, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py config3, per launch means",
+    total = 0.0
+    for k in set(fetch) | set(write):
+        launches = max(len(fetch.get(k, [])), len(write.get(k, [])))
+        if launches < max(frames - 1, 1):
+            first_frame_only.append(short(k))
+            continue
+        per_frame = max(1, round(launches / frames))
+        total += per_frame * (2 * statistics.mean(fetch.get(k, [0.0])) + statistics.mean(write.get(k, [0.0]))) * 1024
+    frame_bytes = round(total)
+json.dump({"frames_sampled": frames, "frame_hbm_bytes_corrected": frame_bytes, "first_frame_only_kernels": sorted(first_frame_only), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py config3, per launch means",
            "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
 if frame_bytes:
-    print(f"one frame, all kernels: {frame_bytes/1e6:.1f} MB corrected over {frames} sampled frames")
+    print(f"one steady frame, all kernels: {frame_bytes/1e6:.1f} MB corrected ({frames} sampled frames; first-frame-only kernels left out: {len(first_frame_only)})")
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_corrected"])[:12]:
     print(f"{k:40s} fetch_raw {v['FETCH_SIZE_bytes_raw']/1e6:8.1f} MB  write {v['WRITE_SIZE_bytes']/1e6:8.1f} MB  corrected {v['hbm_bytes_corrected']/1e6:8.1f} MB")
