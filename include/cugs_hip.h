@@ -164,8 +164,13 @@ int cugs_sort_pairs_predicted(int64_t n, int64_t capacity, const float* means_2d
 
 /* cugs_sort_pairs_predicted on a `workspace` that cugs_project_forward_keyed filled for these arrays (same n, same
  * width x height) on this stream since the last sort that used it: the per-Gaussian key / rectangle launch is
- * skipped (one kernel and 40 MB per million Gaussians).  Outputs, validity rule and both fallbacks are those of
- * cugs_sort_pairs_predicted (the fallbacks rebuild the keys from the arrays). */
+ * skipped (one kernel and 40 MB per million Gaussians).  Outputs and validity rule are those of
+ * cugs_sort_pairs_predicted.  BOTH fallbacks (a count above the capacity, or -1) are cugs_sort_count_pairs followed by
+ * cugs_sort_pairs, which rebuild everything from the arrays: on images of up to 10 240 tiles and up to 2 M Gaussians this
+ * entry point bins the pairs straight into their tiles' lists (no pair-level radix passes, csrc/sort.hip k_bin_*) and
+ * does not leave in `workspace` what cugs_sort_pairs alone continues from.  On either miss every tile range is {0,0}:
+ * a blend queued behind the sort before the host has looked at the count then does nothing (the index buffer is
+ * unwritten).  pair_workspace is not touched on that route (it may still be sized as for cugs_sort_pairs_predicted). */
 int cugs_sort_pairs_predicted_keyed(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
                                     const int32_t* radii, const int32_t* tiles_touched, int width, int height,
                                     void* workspace, size_t workspace_bytes, void* pair_workspace,
