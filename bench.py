@@ -391,7 +391,7 @@ def exchange_payload(mode: str, n: int, c: int, world: int) -> dict:
 
 
 def parse_rccl_log(paths) -> dict:
-    """Which algorithm / protocol RCCL picked, from NCCL_DEBUG=INFO lines (NCCL_DEBUG_SUBSYS=INIT,COLL,TUNING written to
+    """Which algorithm / protocol RCCL picked, from NCCL_DEBUG=INFO lines (NCCL_DEBUG_SUBSYS=INIT,TUNING written to
     NCCL_DEBUG_FILE).  The wording differs between RCCL versions; every line that names a collective together with an
     algorithm and a protocol is taken, numeric ids mapped to names.  Returns {collective: ["Ring/Simple", ...]} plus the
     channel count if announced; {} when nothing could be read (then only the raw tail is kept)."""
@@ -560,7 +560,7 @@ def main():
         rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cugs_bench_rccl_{os.getpid()}_%h_%p.log")
         if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):      # a box default of WARN/VERSION is
             os.environ["NCCL_DEBUG"] = "INFO"                                       # replaced; a louder user setting kept
-        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")     # not COLL: a line per call and rank inside the timed region
         os.environ["NCCL_DEBUG_FILE"] = rccl_log
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))

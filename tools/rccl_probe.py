@@ -1,6 +1,6 @@
 import os, sys, glob
 os.environ["NCCL_DEBUG"] = "INFO"
-os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,COLL,TUNING"
+os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,TUNING"
 os.environ["NCCL_DEBUG_FILE"] = "/tmp/probe_rccl_%h_%p.log"
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 import torch, torch.distributed as dist
