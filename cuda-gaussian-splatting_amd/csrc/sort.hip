@@ -1358,6 +1358,9 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
 }
 
 #ifdef CUGS_DEV
+std::atomic<void*> g_mark_event{nullptr};         // development build: an event recorded right before k_bin_scatter
+#endif
+#ifdef CUGS_DEV
 inline uint32_t bin_ablate() { const char* e = std::getenv("CUGS_BIN_ABLATE"); return e ? (uint32_t)std::atoi(e) : 0u; }
 #else
 constexpr uint32_t bin_ablate() { return 0u; }
@@ -1401,6 +1404,10 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         const uint32_t nbx = ((uint32_t)ntx + BIN_BLK - 1u) / BIN_BLK, nby = ((uint32_t)nty + BIN_BLK - 1u) / BIN_BLK;
         const uint32_t gxs = (nbx + BIN_WG_WAVES - 1u) / BIN_WG_WAVES;
         const uint32_t waves = (nbx + gxs - 1u) / gxs;
+#ifdef CUGS_DEV
+        if (hipEvent_t mark = static_cast<hipEvent_t>(g_mark_event.load(std::memory_order_relaxed)))   // tools/late_colour.py
+            CUGS_RETURN_IF_HIP(hipEventRecord(mark, st));
+#endif
         hipLaunchKernelGGL(k_bin_scatter, dim3(bin_rows(un) * nby * gxs), dim3(waves * CUGS_WAVE), 0, st, un, bin_group(), nbx, nby, gxs,
                            up, dev_count != nullptr, order, static_cast<const uint32_t*>(ws.prect[1]), (uint32_t)ntx, (uint32_t)nty,
                            ws.bin_table, ws.bin_ttot, ws.bin_tpre, ws.bin_csum, zsnap, ws.bin_tbase, ws.total, total_mapped,
@@ -1798,6 +1805,8 @@ extern "C" int cugs_sort_pairs_predicted_wide(int64_t n, int64_t capacity, const
 }
 
 #ifdef CUGS_DEV
+// Development build only: a hipEvent_t the keyed predicted sort records on its stream right before k_bin_scatter (NULL: none).
+extern "C" int cugsdbg_sort_mark_event(void* event) { g_mark_event.store(event, std::memory_order_relaxed); return 0; }
 // Development build only: 0 = never take the direct-binning route, 1 = take it where it applies; returns the setting.
 extern "C" int cugsdbg_sort_direct_route(int on) {
     if (on == 0 || on == 1) g_direct_route.store(on, std::memory_order_relaxed);
