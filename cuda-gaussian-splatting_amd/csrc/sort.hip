@@ -39,6 +39,11 @@ constexpr int CHUNK_MIN = CUGS_BLOCK * IPT;       // 4096 items per workgroup: d
 #ifndef CUGS_PAIR_CHUNK_MULT
 #define CUGS_PAIR_CHUNK_MULT 1
 #endif
+#ifndef CUGS_DEPTH_CHUNK
+#define CUGS_DEPTH_CHUNK 4096
+#endif
+constexpr int CHUNK_DEPTH = CUGS_DEPTH_CHUNK;     // items per workgroup in the three 9-bit depth passes
+static_assert(CHUNK_DEPTH <= CHUNK_MIN && CHUNK_MIN % CHUNK_DEPTH == 0, "the histogram buffers are carved for CHUNK_DEPTH blocks");
 constexpr int CHUNK_PAIR = CUGS_PAIR_CHUNK_MULT * CHUNK_MIN;   // pair-level passes (8192 / 16384: 4 % / 30 % slower, profiles/README.md)
 constexpr int FILL_CHUNK = CUGS_BLOCK;            // Gaussians per workgroup in scan/fill (one per thread)
 #ifndef CUGS_COL_WAVES
@@ -146,8 +151,8 @@ SortWsN carve_n(void* base, int64_t n) {
     for (int i = 0; i < 2; ++i) w.prect[i] = c.take<uint32_t>((size_t)n);
     w.tot = c.take<uint32_t>(RADIX_DEPTH);
     w.blocksum = c.take<uint32_t>((size_t)nblocks_for(n, FILL_CHUNK) + 2);
-    w.hist = c.take<uint32_t>((size_t)RADIX_DEPTH * (nblocks_for(n, CHUNK_MIN) + 1));
-    w.sup_entries = (uint32_t)RADIX_DEPTH * sup_rows_bound(nblocks_for(n, CHUNK_MIN));
+    w.hist = c.take<uint32_t>((size_t)RADIX_DEPTH * (nblocks_for(n, CHUNK_DEPTH) + 1));
+    w.sup_entries = (uint32_t)RADIX_DEPTH * sup_rows_bound(nblocks_for(n, CHUNK_DEPTH));
     w.sup = c.take<uint32_t>((size_t)SUP_TABLES * w.sup_entries);
     w.colhist = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
     w.colscan = c.take<uint32_t>((size_t)RADIX * (nblocks_for(n, COL_CHUNK) + 1));
@@ -1495,7 +1500,7 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
         if (!prekeyed) {
             hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
                                means_2d, radii, tiles_touched, width, height, ntx, nty, ws.dkey[0], ws.rect[0], range_flag,
-                               ws.sup, 3u * sup_used(nblocks_for(un, CHUNK_MIN), RADIX_DEPTH, 1024u >> DEPTH_BITS));
+                               ws.sup, 3u * sup_used(nblocks_for(un, CHUNK_DEPTH), RADIX_DEPTH, 1024u >> DEPTH_BITS));
             CUGS_LAUNCH_CHECK();
         }
         // prekeyed on an image of up to 127 x 127 tiles: the projection left PACKED rectangles (prect[0]) and they ride
@@ -1506,12 +1511,12 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
         // gather stays (profiles/r03_j_packed_rect_ride_ab.log)
         riding = prekeyed && cugs_prect_packable(ntx, nty) && nblocks_for(un, CHUNK_MIN) <= 256u;
         uint32_t* const* pr = ws.prect;
-        const uint32_t used = sup_used(nblocks_for(un, CHUNK_MIN), RADIX_DEPTH, 1024u >> DEPTH_BITS);
+        const uint32_t used = sup_used(nblocks_for(un, CHUNK_DEPTH), RADIX_DEPTH, 1024u >> DEPTH_BITS);
         uint32_t* const sup0 = ws.sup, *const sup1 = ws.sup + used, *const sup2 = ws.sup + 2 * (size_t)used;
-        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, sup0, ws.tot, ws.dkey[1], ws.dval[1], nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, sup1, ws.tot, ws.dkey[0], ws.dval[0], nullptr, st, riding ? pr[1] : nullptr, pr[0]))) return rc;
+        if ((rc = radix_pass<uint32_t, true, 1024, CHUNK_DEPTH, RADIX_DEPTH>(ws.dkey[0], nullptr, un, nullptr, 0, DEPTH_BITS, ws.hist, sup0, ws.tot, ws.dkey[1], ws.dval[1], nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_DEPTH, RADIX_DEPTH>(ws.dkey[1], ws.dval[1], un, nullptr, DEPTH_BITS, DEPTH_BITS, ws.hist, sup1, ws.tot, ws.dkey[0], ws.dval[0], nullptr, st, riding ? pr[1] : nullptr, pr[0]))) return rc;
         // direct: the last pass's histogram kernel also arms the Q12 counter k_bin_count adds to
-        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_MIN, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, sup2, ws.tot, ws.dkey[1], ws.dval[1], direct ? q12 : nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
+        if ((rc = radix_pass<uint32_t, false, 1024, CHUNK_DEPTH, RADIX_DEPTH>(ws.dkey[0], ws.dval[0], un, nullptr, 2 * DEPTH_BITS, DEPTH_BITS, ws.hist, sup2, ws.tot, ws.dkey[1], ws.dval[1], direct ? q12 : nullptr, st, riding ? pr[0] : nullptr, pr[1]))) return rc;
     } else {
         // (1) the general route: four passes of 8 bits on the raw depth bits (positive floats order as unsigned ints)
         hipLaunchKernelGGL(k_depth_keys_rect, dim3(nblocks_for(un, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, un, depths,
@@ -1579,7 +1584,7 @@ int cugs_sort_key_slots(void* workspace, size_t bytes, int64_t n, int width, int
     *prect = packed ? ws.prect[0] : nullptr;
     *range_flag = reinterpret_cast<uint32_t*>(ws.total) + 6;
     *zero = ws.sup;                                // the key kernel also clears the depth passes' super tables
-    *nzero = 3u * sup_used(nblocks_for(n, CHUNK_MIN), RADIX_DEPTH, 1024u >> DEPTH_BITS);       // the three passes of the fast depth route
+    *nzero = 3u * sup_used(nblocks_for(n, CHUNK_DEPTH), RADIX_DEPTH, 1024u >> DEPTH_BITS);       // the three passes of the fast depth route
     return 0;
 }
 
