@@ -246,6 +246,8 @@ def test_render_recovers_from_a_wrong_pair_prediction(pkg, orc, dev):
     (30000, 1600, 1063, -4.2, False),   # config 4's image: 100 x 67 tiles
     (5000, 2032, 2032, -3.0, False),    # 127 x 127 tiles: packable rectangles, but over the direct route's tile limit
     (3000, 3840, 2160, -3.5, False),    # 4K: neither packable nor direct
+    (20000, 2032, 1280, -3.2, False),   # 127 x 80 = 10 160 tiles: 159 chunks of 64 tiles (three scans per wave), 16 block columns
+    (20000, 1280, 2032, -3.2, False),   # 80 x 127: 16 block rows, 10 block columns
     (1_200_000, 640, 360, -5.8, False), # over 1 M Gaussians: the rectangles do not ride through the depth passes,
                                         # k_bin_count gathers and packs them (and writes them out for the scatter)
 ])
