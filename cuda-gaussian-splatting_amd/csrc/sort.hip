@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scan(uint32_t rows, uint32_t til
 // tens of thousands of independent waves that hide each other's latencies.
 // A workgroup is up to eight horizontally adjacent blocks.  Its waves first share out a pre-filter - each takes a slice of the
 // group's records straight from memory and lists in LDS, in order, the ones that touch the workgroup's 8-row, <= 64-column
-// window (one in twelve at 1080p), with their Gaussian index (fetched for those only) - and every wave then tests only
-// the listed ones against its own block.
+// window (one in twelve at 1080p), with their Gaussian index - and every wave then tests only the listed ones against its
+// own block.
 constexpr int BIN_BLK = 8;                        // tile block edge: 64 tiles, one per lane
 constexpr int BIN_WG_WAVES = 8;
 constexpr int BIN_SLICE = 512;                    // records per wave and stage in the pre-filter
@@ -1537,7 +1537,7 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
         uint32_t* const snap = reinterpret_cast<uint32_t*>(ws.total) + 10;   // [0] Q12 pairs, [1] depth range flag
         hipLaunchKernelGGL(k_bin_count, dim3(rows), dim3(BIN_NT), 0, st, un, bin_group(), ws.dval[1], ws.rect[0],
                            riding ? static_cast<const uint32_t*>(ws.prect[1]) : static_cast<const uint32_t*>(nullptr),
-                           ws.prect[1], (uint32_t)ntx, (uint32_t)nty, ws.bin_table, q12);
+                           riding ? static_cast<uint32_t*>(nullptr) : ws.prect[1], (uint32_t)ntx, (uint32_t)nty, ws.bin_table, q12);
         CUGS_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bin_scan, dim3((tiles + CUGS_WAVE - 1) / CUGS_WAVE), dim3(BIN_NT), 0, st, rows, tiles, ws.bin_table,
                            ws.bin_ttot, ws.bin_tpre, ws.bin_csum, q12, range_flag, snap);
