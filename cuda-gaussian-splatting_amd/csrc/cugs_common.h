@@ -12,7 +12,9 @@
 #include "../../include/cugs_hip.h"
 #include "../../include/cugs_detmath.h"
 
-#define CUGS_BLOCK 256
+#ifndef CUGS_BLOCK
+#define CUGS_BLOCK 256     /* threads per workgroup; a translation unit may be built with another value (A/B builds) */
+#endif
 #define CUGS_WAVE 64
 
 // Launch-error convention of the reference (CUDA_CHECK(cudaGetLastError()), projection.cu:267):
