@@ -128,7 +128,13 @@ inline uint32_t bin_group() {
 #endif
     return BIN_GROUP;
 }
-inline bool bin_route_n(int64_t n) { return n <= (int64_t)bin_group() * BIN_ROWS_MAX; }
+inline uint32_t bin_rows_max() {
+#ifdef CUGS_DEV
+    if (const char* e = std::getenv("CUGS_BIN_ROWS_MAX")) return (uint32_t)std::atoi(e);   // development build: sweeps
+#endif
+    return BIN_ROWS_MAX;
+}
+inline bool bin_route_n(int64_t n) { return n <= (int64_t)bin_group() * bin_rows_max(); }
 inline uint32_t bin_rows(uint32_t n) { return (n + bin_group() - 1u) / bin_group(); }
 inline uint32_t bin_table_rows(int64_t n) { return n > 0 && bin_route_n(n) ? bin_rows((uint32_t)n) : 1u; }
 
