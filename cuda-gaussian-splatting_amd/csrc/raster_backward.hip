@@ -33,6 +33,8 @@
 // differences from the oracle's divisions, far inside the 1e-4 bar.
 #include "cugs_raster_common.h"
 
+#include <cstdlib>
+
 #ifdef CUGS_DEV
 bool cugs_dev_backward_stats();
 #endif
@@ -72,6 +74,11 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     __shared__ float4 s_rec[CUGS_BLOCK * CUGS_REC_F4];
     __shared__ float2 s_contrib[4][CUGS_BWD_HITS][CUGS_BWD_HSTRIDE];
 
+#ifdef CUGS_DEV
+    const bool no_atomics = stats_row == -2;       // development build: the kernel without its scatter (timing only; tools/ablate_backward.py)
+#else
+    constexpr bool no_atomics = false;
+#endif
     const unsigned tile = cugs_blend_tile(blockIdx.x, (unsigned)geo.ntx, (unsigned)(geo.ntiles / geo.ntx));
     const int tile_x = (int)(tile % (unsigned)geo.ntx), tile_y = (int)(tile / (unsigned)geo.ntx);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
         M1 *= tail.y; Mxx *= tail.y;
         const float M1y = dy * oA, Myy = dy * M1y, Mxy = dy * M1;
         const float total = reduce9r16(RA, RB, R2, A, M1, M1y, Mxx, Myy, Mxy, lane);
-        if (slot2 >= 0 && h2 < cnt) {
+        if (slot2 >= 0 && h2 < cnt && !no_atomics) {
             const int g = __float_as_int(tail.w);
             if (WIDE) {
                 atomicAdd(grad_accum + (int64_t)g * CUGS_GRAD_STRIDE + slot2, total);
@@ -308,9 +315,13 @@ int rasterize_backward_impl(int width, int height, const float background_host[3
         RasterGeom geo{width, height, ntx, ntx * nty, background_host[0], background_host[1], background_host[2]};
         RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act};
         const bool wide = rows > (int64_t(1) << 26);            // 64-byte rows beyond a 32-bit byte offset
+        int64_t stats_arg = n;                                  // STATS builds: the row that takes the counters
+#ifdef CUGS_DEV
+        if (const char* e = std::getenv("CUGS_BWD_NO_ATOMICS")) if (e[0] == '1') stats_arg = -2;
+#endif
 #define CUGS_LAUNCH_BWD(P, W, S)                                                                              \
     hipLaunchKernelGGL((k_raster_backward<P, W, S>), dim3(geo.ntiles), dim3(CUGS_BLOCK), 0, st, geo, src, \
-                       dL_dcolor, final_T, n_contrib, grad_accum, n)
+                       dL_dcolor, final_T, n_contrib, grad_accum, stats_arg)
 #ifdef CUGS_DEV
         if (stats) {
             if (packed) CUGS_LAUNCH_BWD(true, true, true); else CUGS_LAUNCH_BWD(false, true, true);
