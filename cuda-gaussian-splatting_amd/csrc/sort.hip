@@ -1094,6 +1094,19 @@ constexpr int BIN_BLK = 8;                        // tile block edge: 64 tiles, 
 constexpr int BIN_WG_WAVES = 8;
 constexpr int BIN_SLICE = 512;                    // records per wave and stage in the pre-filter
 constexpr int BIN_SLICE_STEPS = BIN_SLICE / CUGS_WAVE;
+// STAGE (dense views: from BIN_STAGE_RATIO pairs per Gaussian on): a lane collects the indices for its tile in LDS and
+// writes them sixteen at a time - one 64-byte run of its tile's list - instead of one scattered 4-byte store per pair
+// (45 M of those are two thirds of the kernel on the dense 1080p view).  The sparse views keep the direct stores: their
+// (group, tile) runs are ~4 entries long, and the buffer's LDS would halve the resident workgroups.
+#ifndef CUGS_BIN_RUN
+#define CUGS_BIN_RUN 16
+#endif
+constexpr int BIN_RUN = CUGS_BIN_RUN;             // entries a lane collects before the wave writes (16: two workgroups per CU, sort 0.270-0.279 ms
+                                                  // on the dense 1080p view; 8: three per CU, 0.277-0.285; without the buffer 0.345)
+constexpr int BIN_RUN_STRIDE = BIN_RUN + 3;       // LDS row stride in dwords: odd (the lanes' rows start in different banks), and the
+                                                  // flush reads up to three entries beyond `held`
+constexpr uint32_t BIN_STAGE_RATIO = 13u;
+template <bool STAGE>
 __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
     uint32_t n, uint32_t group, uint32_t nbx, uint32_t nby, uint32_t gxs, uint32_t pairs_or_cap, bool predicted,
     const uint32_t* __restrict__ order, const uint32_t* __restrict__ prect, uint32_t ntx, uint32_t nty,
@@ -1103,6 +1116,7 @@ __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
     int32_t* __restrict__ tile_ranges, uint32_t ablate) {
     __shared__ uint2 s_cand[BIN_WG_WAVES][BIN_SLICE];                 // {packed rectangle, Gaussian} of the listed records
     __shared__ uint32_t s_cnt[BIN_WG_WAVES];
+    __shared__ uint32_t s_run[STAGE ? BIN_WG_WAVES * CUGS_WAVE * BIN_RUN_STRIDE + 4 : 1];   // (+ the read-ahead of the last row's flush)
 #ifdef CUGS_DEV
     const uint32_t abl = ablate;                                      // tools/ablate_bin.py
 #else
@@ -1184,6 +1198,8 @@ __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
     const uint32_t blk_x0 = bx * BIN_BLK, blk_x1 = blk_x0 + BIN_BLK;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     char* const outb = reinterpret_cast<char*>(out);
+    uint32_t* const run = s_run + (STAGE ? tid * BIN_RUN_STRIDE : 0u);      // STAGE: this lane's collected indices
+    uint32_t held = 0u;
     const uint32_t base = blk * group;
     const uint32_t end = min(n, base + group);                        // base < end: the grid covers ceil(n / group) groups
     const uint32_t stage = nw * BIN_SLICE;
@@ -1231,13 +1247,36 @@ __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
                     const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)rec.y, l);
                     const uint32_t x0 = prl & 127u, y0 = (prl >> 7) & 127u, w = (prl >> 14) & 127u, h = (prl >> 21) & 127u;
                     const bool in = ((tx - x0) < w) & ((ty - y0) < h);     // unsigned: inside the rectangle
-                    if (in) {
+                    if constexpr (STAGE) {
+                        if (in) run[held++] = g;
+                        if (__ballot(held == (uint32_t)BIN_RUN) != 0ull) {
+                            // one lane's row is full: EVERY lane writes the whole 16-byte pieces it holds (all lanes at
+                            // once - a flush by the one or two full lanes alone is a string of nearly empty instructions)
+                            // and keeps the up to three entries left over
+                            const uint32_t whole = held & ~3u;
+#pragma unroll
+                            for (int q = 0; q < BIN_RUN; q += 4)
+                                if ((uint32_t)q < whole && !(abl & 1u))
+                                    *reinterpret_cast<uint4*>(outb + pos + 4 * q) = make_uint4(run[q], run[q + 1], run[q + 2], run[q + 3]);
+                            const uint32_t rest = held - whole;
+                            const uint32_t r0 = run[whole], r1 = run[whole + 1u], r2 = run[whole + 2u];   // (reads ahead of `held`: values unused)
+                            if (rest > 0u) run[0] = r0;
+                            if (rest > 1u) run[1] = r1;
+                            if (rest > 2u) run[2] = r2;
+                            pos += 4u * whole;
+                            held = rest;
+                        }
+                    } else if (in) {
                         if (!(abl & 1u)) *reinterpret_cast<uint32_t*>(outb + pos) = g;
                         pos += 4u;
                     }
                 }
             }
         }
+    }
+    if constexpr (STAGE) {                                            // what the lanes still hold
+        for (uint32_t q = 0; __ballot(q < held) != 0ull; ++q)
+            if (q < held && !(abl & 1u)) *reinterpret_cast<uint32_t*>(outb + pos + 4u * q) = run[q];
     }
 }
 
@@ -1369,6 +1408,11 @@ int radix_pass(const K* kin, const uint32_t* vin, uint32_t count, const unsigned
 }
 
 #ifdef CUGS_DEV
+inline bool bin_stage_enabled() { const char* e = std::getenv("CUGS_BIN_NO_STAGE"); return !(e && e[0] == '1'); }   // A/B
+#else
+constexpr bool bin_stage_enabled() { return true; }
+#endif
+#ifdef CUGS_DEV
 std::atomic<void*> g_mark_event{nullptr};         // development build: an event recorded right before k_bin_scatter
 #endif
 #ifdef CUGS_DEV
@@ -1419,10 +1463,15 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         if (hipEvent_t mark = static_cast<hipEvent_t>(g_mark_event.load(std::memory_order_relaxed)))   // tools/late_colour.py
             CUGS_RETURN_IF_HIP(hipEventRecord(mark, st));
 #endif
-        hipLaunchKernelGGL(k_bin_scatter, dim3(bin_rows(un) * nby * gxs), dim3(waves * CUGS_WAVE), 0, st, un, bin_group(), nbx, nby, gxs,
-                           up, dev_count != nullptr, order, static_cast<const uint32_t*>(ws.prect[1]), (uint32_t)ntx, (uint32_t)nty,
-                           ws.bin_table, ws.bin_ttot, ws.bin_tpre, ws.bin_csum, zsnap, ws.bin_tbase, ws.total, total_mapped,
-                           reinterpret_cast<uint32_t*>(values_sorted), tile_ranges, bin_ablate());
+        // (the capacity stands for the pair count in the choice of the variant: it follows the previous frames' counts)
+        const bool staged = (unsigned long long)up >= (unsigned long long)BIN_STAGE_RATIO * un && bin_stage_enabled();
+#define CUGS_LAUNCH_SCATTER(S)                                                                                                        \
+        hipLaunchKernelGGL(k_bin_scatter<S>, dim3(bin_rows(un) * nby * gxs), dim3(waves * CUGS_WAVE), 0, st, un, bin_group(), nbx, nby, gxs, \
+                           up, dev_count != nullptr, order, static_cast<const uint32_t*>(ws.prect[1]), (uint32_t)ntx, (uint32_t)nty,      \
+                           ws.bin_table, ws.bin_ttot, ws.bin_tpre, ws.bin_csum, zsnap, ws.bin_tbase, ws.total, total_mapped,             \
+                           reinterpret_cast<uint32_t*>(values_sorted), tile_ranges, bin_ablate())
+        if (staged) CUGS_LAUNCH_SCATTER(true); else CUGS_LAUNCH_SCATTER(false);
+#undef CUGS_LAUNCH_SCATTER
         CUGS_LAUNCH_CHECK();
         if (keys_sorted) {
             hipLaunchKernelGGL(k_bin_keys, dim3(nblocks_for(up, CUGS_BLOCK)), dim3(CUGS_BLOCK), 0, st, up, dev_count, (uint32_t)tiles,
