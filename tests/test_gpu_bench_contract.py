@@ -50,3 +50,30 @@ def test_keyed_and_unkeyed_routes_agree_on_the_workload():
     """`--unkeyed-sort` (stage-by-stage hand-over) and the default (the projection keys the sort) time the same frame."""
     a, b = _bench("--no-parity"), _bench("--no-parity", "--unkeyed-sort")
     assert a["config"]["pairs"] == b["config"]["pairs"] == 8376524
+
+
+def test_launched_bench_line_on_one_rank():
+    """The driver's N > 1 command shape (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with
+    the ONE rank this box can hold: RCCL comes up on the GPU, the exchange modes are calibrated and timed (their
+    collectives run, over a world of one), stdout carries exactly one JSON line, and the line diagnoses its exchange -
+    bytes per mode, exposed time against the compute-only step, what RCCL's log said (the box exports
+    NCCL_DEBUG=VERSION, which the bench overrides for its own process)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "6", "--warmup", "2", "--rehearse-calibration"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 6 and out["config"]["parallelism"].startswith("dp1-views+rccl-")
+    ex = out["exchange"]
+    assert set(ex["per_mode"]) == {"compact", "compact-early", "allreduce"} and ex["compute_only_ms"] > 0
+    assert ex["per_mode"]["allreduce"]["collectives"][0]["bytes"] == 236 * 1000000      # 59 floats per Gaussian
+    assert ex["rccl"] is not None and "unparsed_tail" not in ex["rccl"] or ex["rccl"].get("channels")
+    assert "cpu_baseline" not in out or out["n_gpus"] == 1
