@@ -108,6 +108,7 @@ def algorithmic_bytes(n, c, p, w, h):
 
 ADAM_LR_SCALE = 0.01  # config 4 / --adam: fraction of the reference's default learning rates (see main)
 COLOUR_OVERLAP = False # --colour-overlap: geometry + colour halves, the colour half on a side stream under the sort (A/B)
+SPATIAL_ORDER = False # --spatial-tile-order
 KEY_SORT = True      # --unkeyed-sort: the stage-by-stage route (the sort derives its keys from the projection's arrays)
 
 
@@ -129,13 +130,14 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     ev[1].record()
     # as in render(): the projection has keyed the sort's workspace, the sort runs on the predicted pair count, the
     # host reads the true one after queueing the blend
+    # ... and - as in render() - leaves the order the blend kernels hand their workgroups out in (longest tile list first)
     srt = R.sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, cam.width, cam.height,
-                                     want_keys=False, keyed_workspace=proj.sort_workspace)
+                                     want_keys=False, keyed_workspace=proj.sort_workspace, want_tile_order=R.TILE_ORDER)
     ev[2].record()
     accum = torch.empty((n, pkg._lib.GRAD_STRIDE), dtype=torch.float32, device=g.device)   # cleared by the forward blend
     blend = lambda s: R.rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
                                           s.gaussian_values_sorted, cam.width, cam.height, settings.background,
-                                          packed=proj.packed, zero_buf=accum)
+                                          packed=proj.packed, zero_buf=accum, tile_order=s.tile_order)
     proj.wait_colour()                     # the blend reads rgb / the colour words of the packed records
     fwd = blend(srt)
     if isinstance(srt, R.PendingSort):
@@ -145,7 +147,8 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     ev[3].record()
     rb = R.rasterize_backward(g, proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, srt.tile_ranges,
                               srt.gaussian_values_sorted, fwd.final_T, fwd.n_contrib, cam.width, cam.height,
-                              settings.background, n, packed=proj.packed, unpack=False, zeroed_accum=accum)
+                              settings.background, n, packed=proj.packed, unpack=False, zeroed_accum=accum,
+                              tile_order=srt.tile_order)
     ev[4].record()
     d_means = torch.empty((n, 2), dtype=torch.float32, device=g.device)
     if opt is not None and not do_allreduce:
@@ -508,6 +511,9 @@ def main():
                          "state (reported as `spinup` in the JSON line; 0 disables)")
     ap.add_argument("--unkeyed-sort", action="store_true",
                     help="A/B: cugs_project_forward + cugs_sort_pairs_predicted instead of their _keyed variants")
+    ap.add_argument("--spatial-tile-order", action="store_true",
+                    help="A/B: the blend kernels' workgroups in the spatial (XCD-interleaved) order instead of longest "
+                         "tile list first")
     ap.add_argument("--colour-overlap", action="store_true",
                     help="A/B: the projection as geometry + colour halves with the colour half on a side stream underneath "
                          "the sort, instead of ONE launch on the main stream (measured slower in round 3: default off)")
@@ -522,9 +528,10 @@ def main():
     ap.add_argument("--launcher-dry-run", action="store_true",
                     help="exercise the N-rank launch + rendezvous + one-JSON-line plumbing over gloo, no GPU work")
     args = ap.parse_args()
-    global KEY_SORT, COLOUR_OVERLAP
+    global KEY_SORT, COLOUR_OVERLAP, SPATIAL_ORDER
     KEY_SORT = not args.unkeyed_sort
     COLOUR_OVERLAP = args.colour_overlap and not args.no_colour_overlap
+    SPATIAL_ORDER = args.spatial_tile_order
 
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run / self_launch
     if args.gpus < 1:
@@ -569,6 +576,8 @@ def main():
 
     ge._ensure_built()
     pkg = ge.load_package()
+    if SPATIAL_ORDER:
+        pkg.rasterizer.TILE_ORDER = False
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

@@ -74,6 +74,13 @@ SIGNATURES = {
                                        C.POINTER(C.c_int64), _P]),
     "cugs_sort_pairs_predicted_keyed": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P,
                                              C.POINTER(C.c_int64), _P]),
+    "cugs_sort_pairs_predicted_keyed_ordered": (_I, [_L, _L, _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P, C.c_size_t, _P, _P, _P,
+                                                     C.POINTER(C.c_int64), _P, _P]),
+    "cugs_tile_order": (_I, [_I, _I, _P, _P, _P]),
+    "cugs_rasterize_forward_ordered": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
+                                            _P, _P, _P, _P, C.c_size_t, _P, _P]),
+    "cugs_rasterize_backward_ordered": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
+                                             _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _P]),
     "cugs_rasterize_forward": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,
                                     _P, _P, _P, _P]),
     "cugs_rasterize_forward_zero": (_I, [_I, _I, C.POINTER(C.c_float), _P, _P, _P, _P, _P, _P, _P,

@@ -160,7 +160,8 @@ SortingOutput sort_gaussians(const torch::Tensor& means_2d, const torch::Tensor&
 ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tensor& cov_2d_inv, const torch::Tensor& rgb,
                                 const torch::Tensor& opacities, const torch::Tensor& tile_ranges,
                                 const torch::Tensor& gaussian_indices, int img_w, int img_h,
-                                const float background[3], const torch::Tensor& packed, const torch::Tensor& zero_buf) {
+                                const float background[3], const torch::Tensor& packed, const torch::Tensor& zero_buf,
+                                const torch::Tensor& tile_order) {
     TORCH_CHECK(means_2d.is_cuda(), "means_2d must be on CUDA");
     ForwardOutput o;
     o.color = torch::empty({img_h, img_w, 3}, fopt(means_2d));
@@ -172,9 +173,23 @@ ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tens
     }
     auto m = means_2d.contiguous(), c = cov_2d_inv.contiguous(), r = rgb.contiguous(), op = opacities.contiguous();
     auto tr = tile_ranges.contiguous(), gi = gaussian_indices.contiguous();
-    if (zero_buf.defined()) {                                   // the blend also clears the backward's accumulator
+    if (zero_buf.defined())                                     // the blend also clears the backward's accumulator
         TORCH_CHECK(zero_buf.is_contiguous() && zero_buf.scalar_type() == torch::kFloat32 && zero_buf.numel() % 4 == 0,
                     "zero_buf must be a contiguous float32 tensor of a multiple of four elements");
+    if (tile_order.defined()) {                                 // workgroups handed out longest tile list first
+        TORCH_CHECK(tile_order.is_contiguous() && tile_order.scalar_type() == torch::kInt32 &&
+                    tile_order.numel() == tr.size(0), "tile_order must be a contiguous [tiles] int32 tensor");
+        check(cugs_rasterize_forward_ordered(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m),
+                                             ptr<float>(c), ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(o.color),
+                                             ptr<float>(o.final_T), ptr<int32_t>(o.n_contrib),
+                                             zero_buf.defined() ? zero_buf.data_ptr() : nullptr,
+                                             zero_buf.defined() ? static_cast<size_t>(zero_buf.numel()) * sizeof(float) : 0,
+                                             reinterpret_cast<const uint32_t*>(tile_order.data_ptr<int32_t>()),
+                                             stream_of(means_2d)),
+              "cugs_rasterize_forward_ordered");
+        return o;
+    }
+    if (zero_buf.defined()) {
         check(cugs_rasterize_forward_zero(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m),
                                           ptr<float>(c), ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(o.color),
                                           ptr<float>(o.final_T), ptr<int32_t>(o.n_contrib), zero_buf.data_ptr(),
@@ -189,13 +204,22 @@ ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tens
     return o;
 }
 
+torch::Tensor tile_order_of(const torch::Tensor& tile_ranges, int img_w, int img_h) {
+    auto tr = tile_ranges.contiguous();
+    auto order = torch::empty({tr.size(0)}, iopt(tile_ranges));
+    if (tr.size(0) > 0)
+        check(cugs_tile_order(img_w, img_h, ptr<int32_t>(tr), reinterpret_cast<uint32_t*>(order.data_ptr<int32_t>()),
+                              stream_of(tile_ranges)), "cugs_tile_order");
+    return order;
+}
+
 RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const torch::Tensor& means_2d,
                                            const torch::Tensor& cov_2d_inv, const torch::Tensor& rgb,
                                            const torch::Tensor& opacities, const torch::Tensor& tile_ranges,
                                            const torch::Tensor& gaussian_indices, const torch::Tensor& final_T,
                                            const torch::Tensor& n_contrib, int img_w, int img_h,
                                            const float background[3], int n_gaussians, const torch::Tensor& packed,
-                                           bool unpack, const torch::Tensor& zeroed_accum) {
+                                           bool unpack, const torch::Tensor& zeroed_accum, const torch::Tensor& tile_order) {
     TORCH_CHECK(dL_dcolor.is_cuda(), "dL_dcolor must be on CUDA");
     const int64_t n = n_gaussians;
     RasterizeBackwardOutput o;
@@ -214,6 +238,19 @@ RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const
     auto g = dL_dcolor.contiguous(), m = means_2d.contiguous(), c = cov_2d_inv.contiguous(), r = rgb.contiguous();
     auto op = opacities.contiguous(), tr = tile_ranges.contiguous(), gi = gaussian_indices.contiguous();
     auto ft = final_T.contiguous(), nc = n_contrib.contiguous();
+    if (tile_order.defined()) {
+        TORCH_CHECK(tile_order.is_contiguous() && tile_order.scalar_type() == torch::kInt32 &&
+                    tile_order.numel() == tr.size(0), "tile_order must be a contiguous [tiles] int32 tensor");
+        check(cugs_rasterize_backward_ordered(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m),
+                                              ptr<float>(c), ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(g),
+                                              ptr<float>(ft), ptr<int32_t>(nc), n, ptr<float>(o.grad_accum),
+                                              ptr<float>(o.dL_drgb), ptr<float>(o.dL_dopacity_act), ptr<float>(o.dL_dmeans_2d),
+                                              ptr<float>(o.dL_dcov_2d_inv), prezeroed ? 1 : 0,
+                                              reinterpret_cast<const uint32_t*>(tile_order.data_ptr<int32_t>()),
+                                              stream_of(dL_dcolor)),
+              "cugs_rasterize_backward_ordered");
+        return o;
+    }
     auto entry = prezeroed ? cugs_rasterize_backward_prezeroed : cugs_rasterize_backward;
     check(entry(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m), ptr<float>(c),
                 ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(g), ptr<float>(ft),
@@ -340,13 +377,14 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     torch::Tensor accum = for_backward ? torch::empty({n, CUGS_GRAD_STRIDE}, fopt(model.positions)) : torch::Tensor();
     auto blend = [&](const SortingOutput& s) {
         return rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
-                                 s.gaussian_values_sorted, w, h, settings.background, proj.packed, accum);
+                                 s.gaussian_values_sorted, w, h, settings.background, proj.packed, accum, s.tile_order);
     };
     SortingOutput srt;
     ForwardOutput fwd;
     const int64_t prev = state.last_pairs < 0 ? 0 : state.last_pairs;
     if (!predicted) {
         srt = sort_gaussians_impl(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h, wide);
+        srt.tile_order = tile_order_of(srt.tile_ranges, w, h);
         fwd = blend(srt);
     } else {
         // capacity = estimate * 1.10 + 64 Ki, HELD while the estimate drifts below it (down to 80 %) and grown with 5 %
@@ -364,10 +402,21 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
         srt.gaussian_values_sorted = torch::empty({cap}, iopt(proj.means_2d));
         auto ws = workspace(proj.means_2d.device(), cugs_sort_workspace_bytes(n), 0);
         auto wp = workspace(proj.means_2d.device(), cugs_sort_pair_workspace_bytes(cap), 1);
-        check((wide ? cugs_sort_pairs_predicted_wide : cugs_sort_pairs_predicted_keyed)(
-                  n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii), ptr<int32_t>(tiles), w, h,
-                  ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr, ptr<int32_t>(srt.gaussian_values_sorted),
-                  ptr<int32_t>(srt.tile_ranges), total.data_ptr<int64_t>(), st), "cugs_sort_pairs_predicted");
+        if (wide) {
+            check(cugs_sort_pairs_predicted_wide(
+                      n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii), ptr<int32_t>(tiles), w, h,
+                      ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr, ptr<int32_t>(srt.gaussian_values_sorted),
+                      ptr<int32_t>(srt.tile_ranges), total.data_ptr<int64_t>(), st), "cugs_sort_pairs_predicted_wide");
+            srt.tile_order = tile_order_of(srt.tile_ranges, w, h);
+        } else {
+            // the sort also leaves the order the blend kernels hand their workgroups out in (longest tile list first)
+            srt.tile_order = torch::empty({num_tiles}, iopt(proj.means_2d));
+            check(cugs_sort_pairs_predicted_keyed_ordered(
+                      n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii), ptr<int32_t>(tiles), w, h,
+                      ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr, ptr<int32_t>(srt.gaussian_values_sorted),
+                      ptr<int32_t>(srt.tile_ranges), total.data_ptr<int64_t>(),
+                      reinterpret_cast<uint32_t*>(srt.tile_order.data_ptr<int32_t>()), st), "cugs_sort_pairs_predicted_keyed_ordered");
+        }
         hipEvent_t ev;
         TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
         TORCH_CHECK(hipEventRecord(ev, static_cast<hipStream_t>(st)) == hipSuccess, "hipEventRecord failed");
@@ -386,6 +435,7 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
             if (p == -1) state.wide_left = kWideDepthHold;
             srt = sort_gaussians_impl(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h,
                                       p == -1 || state.wide_left > 0);
+            srt.tile_order = tile_order_of(srt.tile_ranges, w, h);
             fwd = blend(srt);
         }
     }
@@ -395,6 +445,7 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     o.means_2d = proj.means_2d; o.depths = proj.depths; o.cov_2d_inv = proj.cov_2d_inv; o.radii = proj.radii;
     o.rgb = proj.rgb; o.opacities_act = proj.opacities_act;
     o.gaussian_indices = srt.gaussian_values_sorted; o.tile_ranges = srt.tile_ranges; o.packed = proj.packed;
+    o.tile_order = srt.tile_order;
     o.colour_gate = proj.colour_gate;
     o.zeroed_accum = accum;
     if (accum.defined()) o.accum_used = std::make_shared<std::atomic<bool>>(false);
@@ -431,7 +482,7 @@ BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutpu
     if (zeroed.defined() && (zeroed.dim() != 2 || zeroed.size(0) != n)) zeroed = torch::Tensor();
     auto rb = rasterize_backward(dL_dcolor, ro.means_2d, ro.cov_2d_inv, ro.rgb, ro.opacities_act, ro.tile_ranges,
                                  ro.gaussian_indices, ro.final_T, ro.n_contrib, camera.width, camera.height,
-                                 settings.background, static_cast<int>(n), packed, /*unpack=*/false, zeroed);
+                                 settings.background, static_cast<int>(n), packed, /*unpack=*/false, zeroed, ro.tile_order);
     o.dL_dmeans_2d = torch::empty({n, 2}, fopt(dL_dcolor));
     if (fused) {                                                // a8 + a9 + a11 in one launch, parameters updated in place
         const auto& pr = fused->params();

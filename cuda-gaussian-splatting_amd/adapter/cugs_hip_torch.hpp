@@ -28,6 +28,7 @@ struct ProjectionOutput {          // rasterizer/projection.hpp
 struct SortingOutput {             // rasterizer/sorting.hpp:18-24
     torch::Tensor gaussian_keys_sorted, gaussian_values_sorted, tile_ranges;
     int total_pairs = 0;
+    torch::Tensor tile_order;      // [tiles] int32, optional (not in the reference): the tiles, longest list first (cugs_tile_order)
 };
 struct ForwardOutput { torch::Tensor color, final_T, n_contrib; };
 struct RasterizeBackwardOutput {
@@ -51,6 +52,7 @@ struct RenderOutput {              // rasterizer/rasterizer.hpp:27-46
     // copy - finds the flag set and fills a fresh accumulator instead of adding onto the first one's rows.
     mutable torch::Tensor zeroed_accum;
     std::shared_ptr<std::atomic<bool>> accum_used;
+    torch::Tensor tile_order;      // [tiles] int32: the order the blend kernels' workgroups take the tiles in (undefined: spatial)
 };
 struct BackwardOutput { torch::Tensor dL_dpositions, dL_drotations, dL_dscales, dL_dopacities, dL_dsh_coeffs, dL_dmeans_2d; };
 
@@ -64,7 +66,10 @@ ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tens
                                 const torch::Tensor& rgb, const torch::Tensor& opacities,
                                 const torch::Tensor& tile_ranges, const torch::Tensor& gaussian_indices,
                                 int img_w, int img_h, const float background[3],
-                                const torch::Tensor& packed = {}, const torch::Tensor& zero_buf = {});
+                                const torch::Tensor& packed = {}, const torch::Tensor& zero_buf = {},
+                                const torch::Tensor& tile_order = {});
+// the tiles ordered by the length of their lists, longest first, from any valid tile_ranges (cugs_tile_order)
+torch::Tensor tile_order_of(const torch::Tensor& tile_ranges, int img_w, int img_h);
 RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const torch::Tensor& means_2d,
                                            const torch::Tensor& cov_2d_inv, const torch::Tensor& rgb,
                                            const torch::Tensor& opacities, const torch::Tensor& tile_ranges,
@@ -72,7 +77,7 @@ RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const
                                            const torch::Tensor& n_contrib, int img_w, int img_h,
                                            const float background[3], int n_gaussians,
                                            const torch::Tensor& packed = {}, bool unpack = true,
-                                           const torch::Tensor& zeroed_accum = {});
+                                           const torch::Tensor& zeroed_accum = {}, const torch::Tensor& tile_order = {});
 ProjectionBackwardOutput project_backward(const torch::Tensor& dL_dmeans_2d, const torch::Tensor& dL_dcov_2d_inv,
                                           const torch::Tensor& dL_drgb, const torch::Tensor& dL_dopacity_act,
                                           const torch::Tensor& positions, const torch::Tensor& rotations,

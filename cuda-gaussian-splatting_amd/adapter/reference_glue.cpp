@@ -33,6 +33,8 @@ BackwardOutput render_backward(const torch::Tensor& dL_dcolor, const RenderOutpu
                              glue_detail::packed_table().get(ro.color, model.num_gaussians()),
                              glue_detail::packed_table().get_gate(ro.color, model.num_gaussians())};
     h.zeroed_accum = glue_detail::packed_table().take_accum(ro.color, model.num_gaussians());
+    // the reference's struct has no field for the blend kernels' tile order either: one small launch rebuilds it
+    h.tile_order = cugs_hip::tile_order_of(ro.tile_ranges, camera.width, camera.height);
     auto b = cugs_hip::render_backward(dL_dcolor, h, tensors_of(model), to_pod(camera), settings_of(settings));
     return BackwardOutput{b.dL_dpositions, b.dL_drotations, b.dL_dscales, b.dL_dopacities, b.dL_dsh_coeffs, b.dL_dmeans_2d};
 }

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
 #else
     constexpr bool no_atomics = false;
 #endif
-    const unsigned tile = cugs_blend_tile(blockIdx.x, (unsigned)geo.ntx, (unsigned)(geo.ntiles / geo.ntx));
+    const unsigned tile = src.tile_order ? src.tile_order[blockIdx.x]      // heaviest first (cugs_tile_order), else spatial
+                                         : cugs_blend_tile(blockIdx.x, (unsigned)geo.ntx, (unsigned)(geo.ntiles / geo.ntx));
     const int tile_x = (int)(tile % (unsigned)geo.ntx), tile_y = (int)(tile / (unsigned)geo.ntx);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int quad_x = tile_x * CUGS_TILE + (wave & 1) * 8, quad_y = tile_y * CUGS_TILE + (wave >> 1) * 8;
@@ -288,7 +289,7 @@ int rasterize_backward_impl(int width, int height, const float background_host[3
                                        const float* dL_dcolor, const float* final_T,
                                        const int32_t* n_contrib, int64_t n, float* grad_accum,
                                        float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
-                                       float* dL_dcov_2d_inv, bool prezeroed, void* stream) {
+                                       float* dL_dcov_2d_inv, bool prezeroed, const uint32_t* tile_order, void* stream) {
     if (width < 0 || height < 0 || n < 0 || !background_host) return CUGS_EINVAL;
     if (n == 0) return 0;
     if (!grad_accum) return CUGS_EINVAL;
@@ -313,7 +314,7 @@ int rasterize_backward_impl(int width, int height, const float background_host[3
         if (!packed && (!means_2d || !cov_2d_inv || !rgb || !opacities_act)) return CUGS_EINVAL;
         if ((int64_t)width * height > 2147483647ll / 3) return CUGS_EOVERFLOW;
         RasterGeom geo{width, height, ntx, ntx * nty, background_host[0], background_host[1], background_host[2]};
-        RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act};
+        RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act, tile_order};
         const bool wide = rows > (int64_t(1) << 26);            // 64-byte rows beyond a 32-bit byte offset
         int64_t stats_arg = n;                                  // STATS builds: the row that takes the counters
 #ifdef CUGS_DEV
@@ -360,7 +361,7 @@ extern "C" int cugs_rasterize_backward(int width, int height, const float backgr
                                        float* dL_dcov_2d_inv, void* stream) {
     return rasterize_backward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
                                    opacities_act, packed, dL_dcolor, final_T, n_contrib, n, grad_accum, dL_drgb,
-                                   dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv, false, stream);
+                                   dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv, false, nullptr, stream);
 }
 
 extern "C" int cugs_rasterize_backward_prezeroed(int width, int height, const float background_host[3],
@@ -373,7 +374,21 @@ extern "C" int cugs_rasterize_backward_prezeroed(int width, int height, const fl
                                                  float* dL_dcov_2d_inv, void* stream) {
     return rasterize_backward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
                                    opacities_act, packed, dL_dcolor, final_T, n_contrib, n, grad_accum, dL_drgb,
-                                   dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv, true, stream);
+                                   dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv, true, nullptr, stream);
+}
+
+extern "C" int cugs_rasterize_backward_ordered(int width, int height, const float background_host[3],
+                                               const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                                               const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                               const float* opacities_act, const float* packed,
+                                               const float* dL_dcolor, const float* final_T,
+                                               const int32_t* n_contrib, int64_t n, float* grad_accum,
+                                               float* dL_drgb, float* dL_dopacity_act, float* dL_dmeans_2d,
+                                               float* dL_dcov_2d_inv, int prezeroed, const uint32_t* tile_order,
+                                               void* stream) {
+    return rasterize_backward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
+                                   opacities_act, packed, dL_dcolor, final_T, n_contrib, n, grad_accum, dL_drgb,
+                                   dL_dopacity_act, dL_dmeans_2d, dL_dcov_2d_inv, prezeroed != 0, tile_order, stream);
 }
 
 #ifdef CUGS_DEV

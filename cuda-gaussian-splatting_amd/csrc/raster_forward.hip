@@ -32,7 +32,9 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_forward(RasterGeom geo, R
         for (uint32_t e = lo + threadIdx.x; e < hi; e += CUGS_BLOCK) cugs_stnt(zero_buf + e, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     }
 
-    const unsigned tile = cugs_blend_tile(blockIdx.x, (unsigned)geo.ntx, (unsigned)(geo.ntiles / geo.ntx));
+    // heaviest tile first when the caller brings an order (cugs_tile_order: kernel-uniform), else the spatial order
+    const unsigned tile = src.tile_order ? src.tile_order[blockIdx.x]
+                                         : cugs_blend_tile(blockIdx.x, (unsigned)geo.ntx, (unsigned)(geo.ntiles / geo.ntx));
     const int tile_x = (int)(tile % (unsigned)geo.ntx), tile_y = (int)(tile / (unsigned)geo.ntx);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int quad_x = tile_x * CUGS_TILE + (wave & 1) * 8, quad_y = tile_y * CUGS_TILE + (wave >> 1) * 8;
@@ -112,7 +114,8 @@ namespace {
 int rasterize_forward_impl(int width, int height, const float background_host[3], const int32_t* tile_ranges,
                            const int32_t* gaussian_indices, const float* means_2d, const float* cov_2d_inv,
                            const float* rgb, const float* opacities_act, const float* packed, float* out_color,
-                           float* out_final_T, int32_t* out_n_contrib, void* zero_buf, size_t zero_bytes, void* stream) {
+                           float* out_final_T, int32_t* out_n_contrib, void* zero_buf, size_t zero_bytes,
+                           const uint32_t* tile_order, void* stream) {
     if (width < 0 || height < 0 || !background_host) return CUGS_EINVAL;
     if (zero_bytes && (!zero_buf || (reinterpret_cast<uintptr_t>(zero_buf) & 15u) || (zero_bytes & 15u) ||
                        zero_bytes / 16 > 0xFFFFFFFFull))
@@ -129,7 +132,7 @@ int rasterize_forward_impl(int width, int height, const float background_host[3]
     if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
     if ((int64_t)width * height > 2147483647ll / 3) return CUGS_EOVERFLOW;
     RasterGeom geo{width, height, ntx, ntx * nty, background_host[0], background_host[1], background_host[2]};
-    RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act};
+    RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act, tile_order};
     hipStream_t st = static_cast<hipStream_t>(stream);
     float4* zb = zero_bytes ? static_cast<float4*>(zero_buf) : nullptr;
     const uint32_t zv = (uint32_t)(zero_bytes / 16);
@@ -150,7 +153,7 @@ extern "C" int cugs_rasterize_forward(int width, int height, const float backgro
                                       const float* opacities_act, const float* packed, float* out_color,
                                       float* out_final_T, int32_t* out_n_contrib, void* stream) {
     return rasterize_forward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
-                                  opacities_act, packed, out_color, out_final_T, out_n_contrib, nullptr, 0, stream);
+                                  opacities_act, packed, out_color, out_final_T, out_n_contrib, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int cugs_rasterize_forward_zero(int width, int height, const float background_host[3],
@@ -160,5 +163,16 @@ extern "C" int cugs_rasterize_forward_zero(int width, int height, const float ba
                                            float* out_final_T, int32_t* out_n_contrib, void* zero_buf,
                                            size_t zero_bytes, void* stream) {
     return rasterize_forward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
-                                  opacities_act, packed, out_color, out_final_T, out_n_contrib, zero_buf, zero_bytes, stream);
+                                  opacities_act, packed, out_color, out_final_T, out_n_contrib, zero_buf, zero_bytes, nullptr, stream);
+}
+
+extern "C" int cugs_rasterize_forward_ordered(int width, int height, const float background_host[3],
+                                              const int32_t* tile_ranges, const int32_t* gaussian_indices,
+                                              const float* means_2d, const float* cov_2d_inv, const float* rgb,
+                                              const float* opacities_act, const float* packed, float* out_color,
+                                              float* out_final_T, int32_t* out_n_contrib, void* zero_buf,
+                                              size_t zero_bytes, const uint32_t* tile_order, void* stream) {
+    return rasterize_forward_impl(width, height, background_host, tile_ranges, gaussian_indices, means_2d, cov_2d_inv, rgb,
+                                  opacities_act, packed, out_color, out_final_T, out_n_contrib, zero_buf, zero_bytes, tile_order,
+                                  stream);
 }

@@ -239,11 +239,29 @@ def evaluate_sh_backward_cuda(degree: int, sh_coeffs: torch.Tensor, directions: 
     return out
 
 
+# The blend kernels hand their workgroups out in the order of an optional [tiles] int32 tensor: the tiles sorted by the
+# length of their lists, longest first (cugs_tile_order; render() asks the sort for it).  On views whose splats cluster
+# the kernels run a quarter shorter, on uniform ones the same; the results do not depend on the order.
+TILE_ORDER = True
+
+
+def tile_order_of(tile_ranges: torch.Tensor, img_w: int, img_h: int) -> Optional[torch.Tensor]:
+    """The tiles ordered by list length, longest first, from any valid `tile_ranges` (one small launch)."""
+    tiles = int(tile_ranges.shape[0])
+    if tiles == 0:
+        return None
+    order = torch.empty((tiles,), dtype=torch.int32, device=tile_ranges.device)
+    check(lib.cugs_tile_order(int(img_w), int(img_h), _ptr(tile_ranges.contiguous()), _ptr(order), _stream(tile_ranges.device)),
+          "cugs_tile_order")
+    return order
+
+
 def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Tensor,
                    tiles_touched: torch.Tensor, img_w: int, img_h: int, want_keys: bool = True,
-                   wide_depth: bool = False) -> SortingOutput:
+                   wide_depth: bool = False, want_tile_order: bool = False) -> SortingOutput:
     """`wide_depth` (not in the reference): the caller knows that this view's depths leave the range of the three-pass
-    depth ordering (an earlier sort reported -1): the general route at once (cugs_sort_count_pairs_wide)."""
+    depth ordering (an earlier sort reported -1): the general route at once (cugs_sort_count_pairs_wide).
+    `want_tile_order` (not in the reference): also SortingOutput.tile_order (tile_order_of)."""
     _torch_check(means_2d.is_cuda, "means_2d must be on CUDA")
     n = int(means_2d.shape[0])
     dev = means_2d.device
@@ -273,7 +291,8 @@ def sort_gaussians(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Te
                                   int(img_h), _ptr(ws), ws.numel(), _ptr(wp), wp.numel(),
                                   _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals), _ptr(tile_ranges), st),
               "cugs_sort_pairs")
-    return SortingOutput(keys, vals, tile_ranges, p)
+    return SortingOutput(keys, vals, tile_ranges, p,
+                         tile_order=tile_order_of(tile_ranges, img_w, img_h) if want_tile_order else None)
 
 
 # --------------------------------------------------------------------------------------
@@ -317,10 +336,11 @@ class PendingSort:
     valid the prediction was too small and everything launched on these buffers must be redone with the
     returned (exact) SortingOutput."""
 
-    def __init__(self, args, keys, vals, tile_ranges, capacity, slot, event, state_key):
+    def __init__(self, args, keys, vals, tile_ranges, capacity, slot, event, state_key, tile_order=None):
         self._args, self._keys, self._vals, self.tile_ranges = args, keys, vals, tile_ranges
         self.capacity, self._slot, self._event, self._key = capacity, slot, event, state_key
         self.gaussian_values_sorted = vals
+        self.tile_order = tile_order         # [tiles] int32 or None: valid together with tile_ranges (misses included)
         self.wide_depth_found = False        # finish(): the miss was a depth outside the three-pass range
 
     def finish(self):
@@ -334,7 +354,8 @@ class PendingSort:
             # view neither misses nor re-sorts
             _wide_depth[self._key] = WIDE_DEPTH_HOLD
             self.wide_depth_found = True
-            out = sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys, wide_depth=True)
+            out = sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys, wide_depth=True,
+                                 want_tile_order=self.tile_order is not None)
             _last_pairs[self._key] = out.total_pairs
             return out, False
         _torch_check(0 <= p <= 2147483647, "pair count exceeds the reference's int indexing")
@@ -342,14 +363,15 @@ class PendingSort:
         _last_pairs[self._key] = p if p > self.capacity else max(p, int(prev * 0.97))
         if p <= self.capacity:
             keys = self._keys[:p] if want_keys else self._keys
-            return SortingOutput(keys, self._vals[:p], self.tile_ranges, p), True
+            return SortingOutput(keys, self._vals[:p], self.tile_ranges, p, tile_order=self.tile_order), True
         return sort_gaussians(means_2d, depths, radii, tiles, img_w, img_h, want_keys,
-                              wide_depth=_wide_depth.get(self._key, 0) > 0), False
+                              wide_depth=_wide_depth.get(self._key, 0) > 0,
+                              want_tile_order=self.tile_order is not None), False
 
 
 def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii: torch.Tensor,
                              tiles_touched: torch.Tensor, img_w: int, img_h: int, want_keys: bool = False,
-                             keyed_workspace: Optional[torch.Tensor] = None):
+                             keyed_workspace: Optional[torch.Tensor] = None, want_tile_order: bool = False):
     """sort_gaussians with the pair count predicted from the previous call on this device.  Returns a
     PendingSort, or (no prediction yet / empty input) a finished SortingOutput.
     `keyed_workspace`: ProjectionOutput.sort_workspace of project_gaussians(..., key_sort=True) for these very arrays
@@ -364,7 +386,8 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
     if wide:
         _wide_depth[key] -= 1                # when it reaches 0 the next sort probes the three-pass route again
     if last is None or n == 0 or ntx * nty == 0:
-        out = sort_gaussians(means_2d, depths, radii, tiles_touched, img_w, img_h, want_keys, wide_depth=wide)
+        out = sort_gaussians(means_2d, depths, radii, tiles_touched, img_w, img_h, want_keys, wide_depth=wide,
+                             want_tile_order=want_tile_order)
         _last_pairs[key] = out.total_pairs
         return out
     cap = _capacity_for(dev, last)
@@ -381,22 +404,33 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
     entry = lib.cugs_sort_pairs_predicted_keyed if keyed_workspace is not None else lib.cugs_sort_pairs_predicted
     if wide:                                 # the general depth route rebuilds its keys from the arrays
         entry = lib.cugs_sort_pairs_predicted_wide
-    check(entry(n, cap, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w), int(img_h), _ptr(ws),
-                ws.numel(), _ptr(wp), wp.numel(), _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals),
-                _ptr(tile_ranges), C.cast(total.data_ptr(), C.POINTER(C.c_int64)), _stream(dev)),
-          "cugs_sort_pairs_predicted")
+    common = (n, cap, _ptr(means_c), _ptr(depths_c), _ptr(radii_c), _ptr(tiles_c), int(img_w), int(img_h), _ptr(ws),
+              ws.numel(), _ptr(wp), wp.numel(), _ptr(keys) if want_keys else C.c_void_p(0), _ptr(vals),
+              _ptr(tile_ranges), C.cast(total.data_ptr(), C.POINTER(C.c_int64)))
+    tile_order = None
+    if want_tile_order and keyed_workspace is not None and not wide:
+        tile_order = torch.empty((ntx * nty,), **i32)          # written by the sort itself (no extra launch)
+        check(lib.cugs_sort_pairs_predicted_keyed_ordered(*common, _ptr(tile_order), _stream(dev)),
+              "cugs_sort_pairs_predicted_keyed_ordered")
+    else:
+        check(entry(*common, _stream(dev)), "cugs_sort_pairs_predicted")
+        if want_tile_order:
+            tile_order = tile_order_of(tile_ranges, img_w, img_h)
     ev = torch.cuda.Event()
     ev.record()
     return PendingSort((means_c, depths_c, radii_c, tiles_c, img_w, img_h, want_keys), keys, vals, tile_ranges, cap, slot, ev,
-                       key)
+                       key, tile_order=tile_order)
 
 
 def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: torch.Tensor,
                       opacities: torch.Tensor, tile_ranges: torch.Tensor, gaussian_indices: torch.Tensor,
                       img_w: int, img_h: int, background: Sequence[float],
-                      packed: Optional[torch.Tensor] = None, zero_buf: Optional[torch.Tensor] = None) -> ForwardOutput:
+                      packed: Optional[torch.Tensor] = None, zero_buf: Optional[torch.Tensor] = None,
+                      tile_order: Optional[torch.Tensor] = None) -> ForwardOutput:
     """`zero_buf` (optional, not in the reference): a contiguous float32 tensor the launch also fills with zeros -
-    the accumulator of the backward blend, cleared for free by this issue-bound kernel (cugs_rasterize_forward_zero)."""
+    the accumulator of the backward blend, cleared for free by this issue-bound kernel (cugs_rasterize_forward_zero).
+    `tile_order` (optional, not in the reference): [tiles] int32, the order the workgroups take the tiles in
+    (tile_order_of / SortingOutput.tile_order: longest list first); the outputs do not depend on it."""
     _torch_check(means_2d.is_cuda, "means_2d must be on CUDA")
     dev = means_2d.device
     color = torch.empty((img_h, img_w, 3), dtype=torch.float32, device=dev)
@@ -410,6 +444,18 @@ def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: tor
     if zero_buf is not None:
         _torch_check(zero_buf.is_contiguous() and zero_buf.dtype == torch.float32 and zero_buf.numel() % 4 == 0,
                      "zero_buf must be a contiguous float32 tensor of a multiple of four elements")
+    if tile_order is not None:
+        _torch_check(tile_order.is_contiguous() and tile_order.dtype == torch.int32 and
+                     tile_order.numel() == tile_ranges.shape[0], "tile_order must be a contiguous [tiles] int32 tensor")
+        check(lib.cugs_rasterize_forward_ordered(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
+                                                 _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
+                                                 _ptr(cov_2d_inv.contiguous()), _ptr(rgb.contiguous()),
+                                                 _ptr(opacities.contiguous()), _ptr(packed), _ptr(color), _ptr(final_T),
+                                                 _ptr(n_contrib), _ptr(zero_buf),
+                                                 zero_buf.numel() * 4 if zero_buf is not None else 0, _ptr(tile_order),
+                                                 _stream(dev)), "cugs_rasterize_forward_ordered")
+        return ForwardOutput(color, final_T, n_contrib)
+    if zero_buf is not None:
         check(lib.cugs_rasterize_forward_zero(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
                                               _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
                                               _ptr(cov_2d_inv.contiguous()), _ptr(rgb.contiguous()),
@@ -430,9 +476,12 @@ def rasterize_backward(dL_dcolor: torch.Tensor, means_2d: torch.Tensor, cov_2d_i
                        gaussian_indices: torch.Tensor, final_T: torch.Tensor, n_contrib: torch.Tensor,
                        img_w: int, img_h: int, background: Sequence[float], n_gaussians: int,
                        packed: Optional[torch.Tensor] = None, unpack: bool = True,
-                       zeroed_accum: Optional[torch.Tensor] = None) -> RasterizeBackwardOutput:
+                       zeroed_accum: Optional[torch.Tensor] = None,
+                       tile_order: Optional[torch.Tensor] = None) -> RasterizeBackwardOutput:
     """`zeroed_accum` (optional, not in the reference): an [N, 16] accumulator that is already all zeros (cleared by
-    rasterize_forward(..., zero_buf=...)): used as is, without the fill."""
+    rasterize_forward(..., zero_buf=...)): used as is, without the fill.
+    `tile_order` (optional, not in the reference): as in rasterize_forward; the sums are the same up to the order of
+    the atomic adds."""
     _torch_check(dL_dcolor.is_cuda, "dL_dcolor must be on CUDA")
     dev = dL_dcolor.device
     n = int(n_gaussians)
@@ -447,7 +496,19 @@ def rasterize_backward(dL_dcolor: torch.Tensor, means_2d: torch.Tensor, cov_2d_i
         d_means, d_cov = torch.empty((n, 2), **f), torch.empty((n, 3), **f)
     else:
         d_rgb = d_opa = d_means = d_cov = None
-    if n > 0:
+    if n > 0 and tile_order is not None:
+        _torch_check(tile_order.is_contiguous() and tile_order.dtype == torch.int32 and
+                     tile_order.numel() == tile_ranges.shape[0], "tile_order must be a contiguous [tiles] int32 tensor")
+        bg = (C.c_float * 3)(*[float(b) for b in background])
+        check(lib.cugs_rasterize_backward_ordered(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
+                                                  _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
+                                                  _ptr(cov_2d_inv.contiguous()), _ptr(rgb.contiguous()),
+                                                  _ptr(opacities.contiguous()), _ptr(packed),
+                                                  _ptr(dL_dcolor.contiguous()), _ptr(final_T.contiguous()),
+                                                  _ptr(n_contrib.contiguous()), n, _ptr(accum), _ptr(d_rgb), _ptr(d_opa),
+                                                  _ptr(d_means), _ptr(d_cov), 1 if zeroed_accum is not None else 0,
+                                                  _ptr(tile_order), _stream(dev)), "cugs_rasterize_backward_ordered")
+    elif n > 0:
         bg = (C.c_float * 3)(*[float(b) for b in background])
         check(entry(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
                                           _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
@@ -581,16 +642,17 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, f
     accum = torch.empty((n, _lib.GRAD_STRIDE), **f) if for_backward else None
     blend = lambda s: rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,
                                         s.gaussian_values_sorted, camera.width, camera.height, settings.background,
-                                        packed=proj.packed, zero_buf=accum)
+                                        packed=proj.packed, zero_buf=accum, tile_order=s.tile_order)
     srt = sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, camera.width,
-                                   camera.height, want_keys=False, keyed_workspace=proj.sort_workspace)
+                                   camera.height, want_keys=False, keyed_workspace=proj.sort_workspace,
+                                   want_tile_order=TILE_ORDER)
     proj.wait_colour()                                   # the blend reads the colour half's outputs
     fwd = blend(srt)                                     # queued behind the sort; the host has not waited yet
     if defer_count and isinstance(srt, PendingSort):
         return RenderOutput(fwd.color, fwd.final_T, fwd.n_contrib, proj.means_2d, proj.depths, proj.cov_2d_inv,
                             proj.radii, proj.rgb, proj.opacities_act, srt.gaussian_values_sorted, srt.tile_ranges,
                             packed=proj.packed, colour_gate=proj.colour_gate, total_pairs=-1, zeroed_accum=accum,
-                            pending=srt)
+                            pending=srt, tile_order=srt.tile_order)
     if isinstance(srt, PendingSort):
         srt, valid = srt.finish()
         if not valid:                                    # prediction too small (e.g. right after densification)
@@ -598,7 +660,7 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, f
     return RenderOutput(fwd.color, fwd.final_T, fwd.n_contrib, proj.means_2d, proj.depths, proj.cov_2d_inv,
                         proj.radii, proj.rgb, proj.opacities_act, srt.gaussian_values_sorted, srt.tile_ranges,
                         packed=proj.packed, colour_gate=proj.colour_gate, total_pairs=srt.total_pairs,
-                        zeroed_accum=accum)
+                        zeroed_accum=accum, tile_order=srt.tile_order)
 
 
 def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: GaussianModel,
@@ -637,7 +699,8 @@ def render_backward(dL_dcolor: torch.Tensor, render_out: RenderOutput, model: Ga
     rb = rasterize_backward(dL_dcolor, render_out.means_2d, render_out.cov_2d_inv, render_out.rgb,
                             render_out.opacities_act, render_out.tile_ranges, render_out.gaussian_indices,
                             render_out.final_T, render_out.n_contrib, camera.width, camera.height,
-                            settings.background, n, packed=render_out.packed, unpack=False, zeroed_accum=zeroed)
+                            settings.background, n, packed=render_out.packed, unpack=False, zeroed_accum=zeroed,
+                            tile_order=getattr(render_out, "tile_order", None))
     d_means_2d = torch.empty((n, 2), **f)
     if fused_adam is not None:
         _torch_check(fused_adam.model_ is model, "fused_adam must have been built on this model")
