@@ -132,7 +132,8 @@ def timed_step(pkg, model, cam, settings, g, events, exchange, do_allreduce, opt
     # host reads the true one after queueing the blend
     # ... and - as in render() - leaves the order the blend kernels hand their workgroups out in (longest tile list first)
     srt = R.sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, cam.width, cam.height,
-                                     want_keys=False, keyed_workspace=proj.sort_workspace, want_tile_order=R.TILE_ORDER)
+                                     want_keys=False, keyed_workspace=proj.sort_workspace,
+                                     want_tile_order=R.wants_tile_order(g.device))
     ev[2].record()
     accum = torch.empty((n, pkg._lib.GRAD_STRIDE), dtype=torch.float32, device=g.device)   # cleared by the forward blend
     blend = lambda s: R.rasterize_forward(proj.means_2d, proj.cov_2d_inv, proj.rgb, proj.opacities_act, s.tile_ranges,

@@ -64,6 +64,7 @@ struct SortState {
     torch::Tensor pinned;
 };
 constexpr int kWideDepthHold = 256;
+constexpr int64_t kTileOrderMinPairs = 2000000;
 SortState& sort_state(const torch::Device& dev) {
     static thread_local auto& states = *new std::map<std::pair<int, void*>, SortState>();
     return states[{dev.index(), static_cast<void*>(c10::hip::getCurrentHIPStream(dev.index()).stream())}];
@@ -178,7 +179,7 @@ ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tens
                     "zero_buf must be a contiguous float32 tensor of a multiple of four elements");
     if (tile_order.defined()) {                                 // workgroups handed out longest tile list first
         TORCH_CHECK(tile_order.is_contiguous() && tile_order.scalar_type() == torch::kInt32 &&
-                    tile_order.numel() == tr.size(0), "tile_order must be a contiguous [tiles] int32 tensor");
+                    tile_order.numel() == 4 * tr.size(0), "tile_order must be a contiguous [tiles, 4] int32 tensor");
         check(cugs_rasterize_forward_ordered(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m),
                                              ptr<float>(c), ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(o.color),
                                              ptr<float>(o.final_T), ptr<int32_t>(o.n_contrib),
@@ -206,7 +207,7 @@ ForwardOutput rasterize_forward(const torch::Tensor& means_2d, const torch::Tens
 
 torch::Tensor tile_order_of(const torch::Tensor& tile_ranges, int img_w, int img_h) {
     auto tr = tile_ranges.contiguous();
-    auto order = torch::empty({tr.size(0)}, iopt(tile_ranges));
+    auto order = torch::empty({tr.size(0), 4}, iopt(tile_ranges));     // {tile, first pair, one past the last, 0}
     if (tr.size(0) > 0)
         check(cugs_tile_order(img_w, img_h, ptr<int32_t>(tr), reinterpret_cast<uint32_t*>(order.data_ptr<int32_t>()),
                               stream_of(tile_ranges)), "cugs_tile_order");
@@ -240,7 +241,7 @@ RasterizeBackwardOutput rasterize_backward(const torch::Tensor& dL_dcolor, const
     auto ft = final_T.contiguous(), nc = n_contrib.contiguous();
     if (tile_order.defined()) {
         TORCH_CHECK(tile_order.is_contiguous() && tile_order.scalar_type() == torch::kInt32 &&
-                    tile_order.numel() == tr.size(0), "tile_order must be a contiguous [tiles] int32 tensor");
+                    tile_order.numel() == 4 * tr.size(0), "tile_order must be a contiguous [tiles, 4] int32 tensor");
         check(cugs_rasterize_backward_ordered(img_w, img_h, background, ptr<int32_t>(tr), ptr<int32_t>(gi), ptr<float>(m),
                                               ptr<float>(c), ptr<float>(r), ptr<float>(op), ptr<float>(packed), ptr<float>(g),
                                               ptr<float>(ft), ptr<int32_t>(nc), n, ptr<float>(o.grad_accum),
@@ -382,9 +383,11 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
     SortingOutput srt;
     ForwardOutput fwd;
     const int64_t prev = state.last_pairs < 0 ? 0 : state.last_pairs;
+    // longest-list-first order for the blend kernels' workgroups: worth making for large frames (~8 us of one workgroup
+    // inside the sort's last kernel, which a small frame does not hide)
+    const bool ordered = prev >= kTileOrderMinPairs;
     if (!predicted) {
         srt = sort_gaussians_impl(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h, wide);
-        srt.tile_order = tile_order_of(srt.tile_ranges, w, h);
         fwd = blend(srt);
     } else {
         // capacity = estimate * 1.10 + 64 Ki, HELD while the estimate drifts below it (down to 80 %) and grown with 5 %
@@ -407,10 +410,15 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
                       n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii), ptr<int32_t>(tiles), w, h,
                       ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr, ptr<int32_t>(srt.gaussian_values_sorted),
                       ptr<int32_t>(srt.tile_ranges), total.data_ptr<int64_t>(), st), "cugs_sort_pairs_predicted_wide");
-            srt.tile_order = tile_order_of(srt.tile_ranges, w, h);
+            if (ordered) srt.tile_order = tile_order_of(srt.tile_ranges, w, h);
+        } else if (!ordered) {
+            check(cugs_sort_pairs_predicted_keyed(
+                      n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii), ptr<int32_t>(tiles), w, h,
+                      ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr, ptr<int32_t>(srt.gaussian_values_sorted),
+                      ptr<int32_t>(srt.tile_ranges), total.data_ptr<int64_t>(), st), "cugs_sort_pairs_predicted_keyed");
         } else {
             // the sort also leaves the order the blend kernels hand their workgroups out in (longest tile list first)
-            srt.tile_order = torch::empty({num_tiles}, iopt(proj.means_2d));
+            srt.tile_order = torch::empty({num_tiles, 4}, iopt(proj.means_2d));
             check(cugs_sort_pairs_predicted_keyed_ordered(
                       n, cap, ptr<float>(proj.means_2d), ptr<float>(proj.depths), ptr<int32_t>(proj.radii), ptr<int32_t>(tiles), w, h,
                       ws.data_ptr(), ws.numel(), wp.data_ptr(), wp.numel(), nullptr, ptr<int32_t>(srt.gaussian_values_sorted),
@@ -435,7 +443,7 @@ RenderOutput render(const ModelTensors& model, const cugs_camera& camera, const 
             if (p == -1) state.wide_left = kWideDepthHold;
             srt = sort_gaussians_impl(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, w, h,
                                       p == -1 || state.wide_left > 0);
-            srt.tile_order = tile_order_of(srt.tile_ranges, w, h);
+            if (ordered) srt.tile_order = tile_order_of(srt.tile_ranges, w, h);
             fwd = blend(srt);
         }
     }

@@ -28,7 +28,7 @@ struct ProjectionOutput {          // rasterizer/projection.hpp
 struct SortingOutput {             // rasterizer/sorting.hpp:18-24
     torch::Tensor gaussian_keys_sorted, gaussian_values_sorted, tile_ranges;
     int total_pairs = 0;
-    torch::Tensor tile_order;      // [tiles] int32, optional (not in the reference): the tiles, longest list first (cugs_tile_order)
+    torch::Tensor tile_order;      // [tiles,4] int32, optional (not in the reference): {tile, first, end, 0}, longest list first (cugs_tile_order)
 };
 struct ForwardOutput { torch::Tensor color, final_T, n_contrib; };
 struct RasterizeBackwardOutput {
@@ -52,7 +52,7 @@ struct RenderOutput {              // rasterizer/rasterizer.hpp:27-46
     // copy - finds the flag set and fills a fresh accumulator instead of adding onto the first one's rows.
     mutable torch::Tensor zeroed_accum;
     std::shared_ptr<std::atomic<bool>> accum_used;
-    torch::Tensor tile_order;      // [tiles] int32: the order the blend kernels' workgroups take the tiles in (undefined: spatial)
+    torch::Tensor tile_order;      // [tiles,4] int32: the order the blend kernels' workgroups take the tiles in (undefined: spatial)
 };
 struct BackwardOutput { torch::Tensor dL_dpositions, dL_drotations, dL_dscales, dL_dopacities, dL_dsh_coeffs, dL_dmeans_2d; };
 

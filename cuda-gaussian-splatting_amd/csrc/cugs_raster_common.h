@@ -32,7 +32,8 @@ struct RasterSrc {
     const float* cov_2d_inv;
     const float* rgb;
     const float* opa;
-    const uint32_t* tile_order; // may be NULL -> the spatial order of cugs_blend_tile; else workgroup b takes tile tile_order[b]
+    const uint4* tile_order;    // may be NULL -> the spatial order of cugs_blend_tile; else workgroup b works on record b:
+                                // {tile, first pair, one past the last pair, 0} - tile and range in ONE load (cugs_tile_order)
 };
 
 // Stage list entry `li` (if < end) into LDS slot threadIdx.x.  The LDS copy of the record carries the

@@ -79,8 +79,17 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
 #else
     constexpr bool no_atomics = false;
 #endif
-    const unsigned tile = src.tile_order ? src.tile_order[blockIdx.x]      // heaviest first (cugs_tile_order), else spatial
-                                         : cugs_blend_tile(blockIdx.x, (unsigned)geo.ntx, (unsigned)(geo.ntiles / geo.ntx));
+    // heaviest tile first when the caller brings an order (cugs_tile_order: kernel-uniform), else the spatial order
+    unsigned tile;
+    int range_start, range_end;
+    if (src.tile_order) {
+        const uint4 rec = src.tile_order[blockIdx.x];
+        tile = rec.x; range_start = (int)rec.y; range_end = (int)rec.z;
+    } else {
+        tile = cugs_blend_tile(blockIdx.x, (unsigned)geo.ntx, (unsigned)(geo.ntiles / geo.ntx));
+        range_start = src.tile_ranges[tile * 2 + 0];
+        range_end = src.tile_ranges[tile * 2 + 1];
+    }
     const int tile_x = (int)(tile % (unsigned)geo.ntx), tile_y = (int)(tile / (unsigned)geo.ntx);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int quad_x = tile_x * CUGS_TILE + (wave & 1) * 8, quad_y = tile_y * CUGS_TILE + (wave >> 1) * 8;
@@ -89,8 +98,6 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_raster_backward(RasterGeom geo, 
     const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
     const float qx0 = (float)quad_x + 0.5f, qy0 = (float)quad_y + 0.5f;
 
-    const int range_start = src.tile_ranges[tile * 2 + 0];
-    const int range_end = src.tile_ranges[tile * 2 + 1];
     const int num_in_range = range_end - range_start;
     const int num_batches = (num_in_range + CUGS_BLOCK - 1) / CUGS_BLOCK;
 
@@ -299,6 +306,7 @@ int rasterize_backward_impl(int width, int height, const float background_host[3
     if (n_soa != 0 && n_soa != 4) return CUGS_EINVAL;
     if (n_soa == 4 && !packed && !cov_2d_inv) return CUGS_EINVAL;
     if (packed && !cugs_aligned16(packed)) return CUGS_EALIGN;
+    if (tile_order && !cugs_aligned16(tile_order)) return CUGS_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int64_t rows = n;
 #ifdef CUGS_DEV
@@ -314,7 +322,7 @@ int rasterize_backward_impl(int width, int height, const float background_host[3
         if (!packed && (!means_2d || !cov_2d_inv || !rgb || !opacities_act)) return CUGS_EINVAL;
         if ((int64_t)width * height > 2147483647ll / 3) return CUGS_EOVERFLOW;
         RasterGeom geo{width, height, ntx, ntx * nty, background_host[0], background_host[1], background_host[2]};
-        RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act, tile_order};
+        RasterSrc src{tile_ranges, gaussian_indices, packed, means_2d, cov_2d_inv, rgb, opacities_act, reinterpret_cast<const uint4*>(tile_order)};
         const bool wide = rows > (int64_t(1) << 26);            // 64-byte rows beyond a 32-bit byte offset
         int64_t stats_arg = n;                                  // STATS builds: the row that takes the counters
 #ifdef CUGS_DEV

@@ -950,8 +950,12 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t len) {
     return 511u - (e * 16u + m);
 }
 // By every thread of ONE workgroup (any size that is a multiple of 64).  s_hist: ORDER_LDS dwords of LDS.
-template <typename LenFn>
-__device__ __forceinline__ void write_tile_order(uint32_t tiles, LenFn len_of, uint32_t* __restrict__ order, uint32_t* s_hist) {
+// A record of the order is {tile, first pair, one past the last pair, 0}: the blend workgroup that takes it has its tile
+// and its range in one 16-byte load (a bare tile id puts a second, dependent memory round trip in front of every
+// workgroup: +6 % on the 100 k-Gaussian forward-only frame, whose workgroups are a few microseconds long).
+template <typename LenFn, typename StartFn>
+__device__ __forceinline__ void write_tile_order(uint32_t tiles, LenFn len_of, StartFn start_of, uint4* __restrict__ order,
+                                                 uint32_t* s_hist) {
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     for (uint32_t b = tid; b < ORDER_LDS; b += nt) s_hist[b] = 0u;
     __syncthreads();
@@ -966,13 +970,17 @@ __device__ __forceinline__ void write_tile_order(uint32_t tiles, LenFn len_of, u
         for (int k = 0; k < 9; ++k) { s_hist[tid * 9u + k] = run; run += v[k]; }
     }
     __syncthreads();
-    for (uint32_t t = tid; t < tiles; t += nt) order[atomicAdd(&s_hist[order_bucket(len_of(t))], 1u)] = t;
+    for (uint32_t t = tid; t < tiles; t += nt) {
+        const uint32_t len = len_of(t), first = len ? start_of(t) : 0u;
+        order[atomicAdd(&s_hist[order_bucket(len)], 1u)] = make_uint4(t, first, first + len, 0u);
+    }
     __syncthreads();
 }
 __global__ __launch_bounds__(1024) void k_tile_order(uint32_t tiles, const int32_t* __restrict__ tile_ranges,
-                                                      uint32_t* __restrict__ order) {
+                                                      uint4* __restrict__ order) {
     __shared__ uint32_t s_hist[ORDER_LDS];
-    write_tile_order(tiles, [&](uint32_t t) { return (uint32_t)(tile_ranges[2 * t + 1] - tile_ranges[2 * t]); }, order, s_hist);
+    write_tile_order(tiles, [&](uint32_t t) { return (uint32_t)(tile_ranges[2 * t + 1] - tile_ranges[2 * t]); },
+                     [&](uint32_t t) { return (uint32_t)tile_ranges[2 * t]; }, order, s_hist);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1233,9 +1241,18 @@ __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
             if (total_mapped) __hip_atomic_store(total_mapped, host_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (tile_order && blockIdx.x == 0u)                               // the blend kernels' workgroup order, by this one workgroup
-        write_tile_order(tiles, [&](uint32_t t2) { return fits ? ttot[t2] + (t2 == 0u ? zero : 0u) : 0u; }, tile_order,
-                         reinterpret_cast<uint32_t*>(&s_cand[0][0]));         // (the candidate lists are not in use yet)
+    if (tile_order && blockIdx.x == 0u) {                             // the blend kernels' workgroup order, by this one workgroup
+        uint32_t* const s_lds = reinterpret_cast<uint32_t*>(&s_cand[0][0]);   // (the candidate lists are not in use yet)
+        uint32_t* const s_chunk = s_lds + ORDER_LDS;                  // exclusive prefix of every chunk, for the tile starts
+        if (wid == 0u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (lane + (uint32_t)i * CUGS_WAVE < nch) s_chunk[lane + (uint32_t)i * CUGS_WAVE] = cpre[i];
+        }
+        write_tile_order(tiles, [&](uint32_t t2) { return fits ? ttot[t2] + (t2 == 0u ? zero : 0u) : 0u; },
+                         [&](uint32_t t2) { return t2 == 0u ? 0u : zero + s_chunk[t2 >> 6] + tpre[t2]; },
+                         reinterpret_cast<uint4*>(tile_order), s_lds);
+    }
     if (!fits) return;
     if (blk == 0u)                                                    // the Q12 slots: (tile 0, Gaussian 0) pairs
         for (uint32_t k = rem * nt + tid; k < zero; k += per_group * nt) out[k] = 0u;
@@ -1825,7 +1842,7 @@ int sort_pairs_predicted_impl(int64_t n, int64_t capacity, const float* means_2d
     // tile_order (optional): every exit that leaves valid ranges also leaves a valid order of the tiles
     auto order_from_ranges = [&]() -> int {
         if (!tile_order) return 0;
-        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (uint32_t)tiles, tile_ranges, tile_order);
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (uint32_t)tiles, tile_ranges, reinterpret_cast<uint4*>(tile_order));
         CUGS_LAUNCH_CHECK();
         return 0;
     };
@@ -1912,8 +1929,8 @@ extern "C" int cugs_sort_pairs_predicted_keyed(int64_t n, int64_t capacity, cons
                                      tile_ranges, total_pairs_host, stream, true);
 }
 
-// cugs_sort_pairs_predicted_keyed that also leaves, in tile_order[tiles], the tiles ordered by the length of their lists,
-// longest first: what cugs_rasterize_forward_ordered / cugs_rasterize_backward_ordered hand their workgroups out by.
+// cugs_sort_pairs_predicted_keyed that also leaves, in tile_order[tiles][4], the tiles ordered by the length of their lists,
+// longest first ({tile, first pair, one past the last pair, 0} each): what cugs_rasterize_forward_ordered / cugs_rasterize_backward_ordered hand their workgroups out by.
 extern "C" int cugs_sort_pairs_predicted_keyed_ordered(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
                                                        const int32_t* radii, const int32_t* tiles_touched, int width,
                                                        int height, void* workspace, size_t workspace_bytes,
@@ -1921,6 +1938,7 @@ extern "C" int cugs_sort_pairs_predicted_keyed_ordered(int64_t n, int64_t capaci
                                                        uint64_t* keys_sorted, int32_t* values_sorted, int32_t* tile_ranges,
                                                        int64_t* total_pairs_host, uint32_t* tile_order, void* stream) {
     if (!tile_order) return CUGS_EINVAL;
+    if (reinterpret_cast<uintptr_t>(tile_order) & 15u) return CUGS_EALIGN;
     return sort_pairs_predicted_impl(n, capacity, means_2d, depths, radii, tiles_touched, width, height, workspace,
                                      workspace_bytes, pair_workspace, pair_workspace_bytes, keys_sorted, values_sorted,
                                      tile_ranges, total_pairs_host, stream, true, false, tile_order);
@@ -1932,7 +1950,9 @@ extern "C" int cugs_tile_order(int width, int height, const int32_t* tile_ranges
     const int64_t tiles = (int64_t)((width + CUGS_TILE - 1) / CUGS_TILE) * ((height + CUGS_TILE - 1) / CUGS_TILE);
     if (tiles == 0) return 0;
     if (!tile_ranges || !tile_order || tiles > 2147483647ll) return CUGS_EINVAL;
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), (uint32_t)tiles, tile_ranges, tile_order);
+    if (reinterpret_cast<uintptr_t>(tile_order) & 15u) return CUGS_EALIGN;
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), (uint32_t)tiles, tile_ranges,
+                       reinterpret_cast<uint4*>(tile_order));
     CUGS_LAUNCH_CHECK();
     return 0;
 }

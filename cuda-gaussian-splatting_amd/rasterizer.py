@@ -239,10 +239,20 @@ def evaluate_sh_backward_cuda(degree: int, sh_coeffs: torch.Tensor, directions: 
     return out
 
 
-# The blend kernels hand their workgroups out in the order of an optional [tiles] int32 tensor: the tiles sorted by the
-# length of their lists, longest first (cugs_tile_order; render() asks the sort for it).  On views whose splats cluster
+# The blend kernels hand their workgroups out in the order of an optional [tiles, 4] int32 tensor: the tiles sorted by the
+# length of their lists, longest first, as records {tile, first pair, one past the last pair, 0} (cugs_tile_order; render()
+# asks the sort for it).  On views whose splats cluster
 # the kernels run a quarter shorter, on uniform ones the same; the results do not depend on the order.
 TILE_ORDER = True
+# ... from this many (predicted) pairs on: making the order is ~8 us of ONE workgroup inside the sort's last kernel, which a
+# large frame hides and a small one does not (100 k Gaussians, forward only: 0.182 ms with the order, 0.165 without)
+TILE_ORDER_MIN_PAIRS = 2_000_000
+
+
+def wants_tile_order(dev) -> bool:
+    """render()'s rule: the order is worth making for frames of TILE_ORDER_MIN_PAIRS pairs or more (last count seen on
+    this stream)."""
+    return bool(TILE_ORDER) and _last_pairs.get(_skey(dev), 0) >= TILE_ORDER_MIN_PAIRS
 
 
 def tile_order_of(tile_ranges: torch.Tensor, img_w: int, img_h: int) -> Optional[torch.Tensor]:
@@ -250,7 +260,7 @@ def tile_order_of(tile_ranges: torch.Tensor, img_w: int, img_h: int) -> Optional
     tiles = int(tile_ranges.shape[0])
     if tiles == 0:
         return None
-    order = torch.empty((tiles,), dtype=torch.int32, device=tile_ranges.device)
+    order = torch.empty((tiles, 4), dtype=torch.int32, device=tile_ranges.device)
     check(lib.cugs_tile_order(int(img_w), int(img_h), _ptr(tile_ranges.contiguous()), _ptr(order), _stream(tile_ranges.device)),
           "cugs_tile_order")
     return order
@@ -409,7 +419,7 @@ def sort_gaussians_predicted(means_2d: torch.Tensor, depths: torch.Tensor, radii
               _ptr(tile_ranges), C.cast(total.data_ptr(), C.POINTER(C.c_int64)))
     tile_order = None
     if want_tile_order and keyed_workspace is not None and not wide:
-        tile_order = torch.empty((ntx * nty,), **i32)          # written by the sort itself (no extra launch)
+        tile_order = torch.empty((ntx * nty, 4), **i32)        # written by the sort itself (no extra launch)
         check(lib.cugs_sort_pairs_predicted_keyed_ordered(*common, _ptr(tile_order), _stream(dev)),
               "cugs_sort_pairs_predicted_keyed_ordered")
     else:
@@ -429,7 +439,7 @@ def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: tor
                       tile_order: Optional[torch.Tensor] = None) -> ForwardOutput:
     """`zero_buf` (optional, not in the reference): a contiguous float32 tensor the launch also fills with zeros -
     the accumulator of the backward blend, cleared for free by this issue-bound kernel (cugs_rasterize_forward_zero).
-    `tile_order` (optional, not in the reference): [tiles] int32, the order the workgroups take the tiles in
+    `tile_order` (optional, not in the reference): [tiles, 4] int32, the order the workgroups take the tiles in
     (tile_order_of / SortingOutput.tile_order: longest list first); the outputs do not depend on it."""
     _torch_check(means_2d.is_cuda, "means_2d must be on CUDA")
     dev = means_2d.device
@@ -446,7 +456,7 @@ def rasterize_forward(means_2d: torch.Tensor, cov_2d_inv: torch.Tensor, rgb: tor
                      "zero_buf must be a contiguous float32 tensor of a multiple of four elements")
     if tile_order is not None:
         _torch_check(tile_order.is_contiguous() and tile_order.dtype == torch.int32 and
-                     tile_order.numel() == tile_ranges.shape[0], "tile_order must be a contiguous [tiles] int32 tensor")
+                     tile_order.numel() == 4 * tile_ranges.shape[0], "tile_order must be a contiguous [tiles, 4] int32 tensor")
         check(lib.cugs_rasterize_forward_ordered(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
                                                  _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
                                                  _ptr(cov_2d_inv.contiguous()), _ptr(rgb.contiguous()),
@@ -498,7 +508,7 @@ def rasterize_backward(dL_dcolor: torch.Tensor, means_2d: torch.Tensor, cov_2d_i
         d_rgb = d_opa = d_means = d_cov = None
     if n > 0 and tile_order is not None:
         _torch_check(tile_order.is_contiguous() and tile_order.dtype == torch.int32 and
-                     tile_order.numel() == tile_ranges.shape[0], "tile_order must be a contiguous [tiles] int32 tensor")
+                     tile_order.numel() == 4 * tile_ranges.shape[0], "tile_order must be a contiguous [tiles, 4] int32 tensor")
         bg = (C.c_float * 3)(*[float(b) for b in background])
         check(lib.cugs_rasterize_backward_ordered(int(img_w), int(img_h), bg, _ptr(tile_ranges.contiguous()),
                                                   _ptr(gaussian_indices.contiguous()), _ptr(means_2d.contiguous()),
@@ -645,7 +655,7 @@ def render(model: GaussianModel, camera: CameraInfo, settings: RenderSettings, f
                                         packed=proj.packed, zero_buf=accum, tile_order=s.tile_order)
     srt = sort_gaussians_predicted(proj.means_2d, proj.depths, proj.radii, proj.tiles_touched, camera.width,
                                    camera.height, want_keys=False, keyed_workspace=proj.sort_workspace,
-                                   want_tile_order=TILE_ORDER)
+                                   want_tile_order=wants_tile_order(dev))
     proj.wait_colour()                                   # the blend reads the colour half's outputs
     fwd = blend(srt)                                     # queued behind the sort; the host has not waited yet
     if defer_count and isinstance(srt, PendingSort):

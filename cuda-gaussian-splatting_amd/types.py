@@ -155,7 +155,7 @@ class SortingOutput:
     gaussian_values_sorted: torch.Tensor    # [P] int32
     tile_ranges: torch.Tensor               # [tiles,2] int32
     total_pairs: int
-    tile_order: Optional[torch.Tensor] = None   # [tiles] int32 (not in the reference): the tiles, longest list first
+    tile_order: Optional[torch.Tensor] = None   # [tiles,4] int32 (not in the reference): {tile, first, end, 0}, longest list first
 
 
 @dataclass
@@ -202,7 +202,7 @@ class RenderOutput:
     total_pairs: int = 0
     zeroed_accum: Optional[torch.Tensor] = None # [N,16] accumulator already cleared by the forward blend (one backward)
     pending: Optional[object] = None            # render(..., defer_count=True): the sort's pair count has not been read yet
-    tile_order: Optional[torch.Tensor] = None   # [tiles] int32: the order the blend kernels' workgroups take the tiles in
+    tile_order: Optional[torch.Tensor] = None   # [tiles,4] int32: the order the blend kernels' workgroups take the tiles in
 
     def wait(self) -> "RenderOutput":
         """Completes a render(..., defer_count=True): waits for the sort's pair count, trims `gaussian_indices` to it

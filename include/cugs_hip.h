@@ -178,11 +178,12 @@ int cugs_sort_pairs_predicted_keyed(int64_t n, int64_t capacity, const float* me
                                     size_t pair_workspace_bytes, uint64_t* keys_sorted, int32_t* values_sorted,
                                     int32_t* tile_ranges, int64_t* total_pairs_host, void* stream);
 
-/* cugs_sort_pairs_predicted_keyed that also leaves in tile_order[tiles] the tiles ordered by the length of their lists,
- * longest first (to 6 %; empty tiles last) - the order cugs_rasterize_forward_ordered / cugs_rasterize_backward_ordered hand
- * their workgroups out by.  Not in the reference; what a render() built on this library calls: on views whose splats
+/* cugs_sort_pairs_predicted_keyed that also leaves in tile_order[tiles][4] (16-byte aligned) the tiles ordered by the
+ * length of their lists, longest first (to 6 %; empty tiles last), as records {tile, first pair, one past the last pair,
+ * 0} - what cugs_rasterize_forward_ordered / cugs_rasterize_backward_ordered hand their workgroups out by (tile and
+ * range in one load).  Not in the reference; what a render() built on this library calls: on views whose splats
  * cluster (every real capture) the blend kernels run a quarter shorter, on uniform ones the same.
- * Whenever the call leaves valid tile ranges it leaves a valid order (a permutation of [0, tiles)), misses included. */
+ * Whenever the call leaves valid tile ranges it leaves a valid order (every tile once, with its range), misses included. */
 int cugs_sort_pairs_predicted_keyed_ordered(int64_t n, int64_t capacity, const float* means_2d, const float* depths,
                                             const int32_t* radii, const int32_t* tiles_touched, int width, int height,
                                             void* workspace, size_t workspace_bytes, void* pair_workspace,
@@ -231,9 +232,9 @@ int cugs_rasterize_forward_zero(int width, int height, const float background_ho
                                 float* out_color, float* out_final_T, int32_t* out_n_contrib,
                                 void* zero_buf, size_t zero_bytes, void* stream);
 
-/* cugs_rasterize_forward_zero whose workgroups take the tiles in the order tile_order[0 .. tiles) (cugs_tile_order /
- * cugs_sort_pairs_predicted_keyed_ordered; NULL: the spatial order).  Any permutation of the tiles is a correct order:
- * the outputs do not depend on it, bit for bit.  zero_buf / zero_bytes may be NULL / 0. */
+/* cugs_rasterize_forward_zero whose workgroups take their tile AND its range from the records tile_order[0 .. tiles)[4]
+ * (cugs_tile_order / cugs_sort_pairs_predicted_keyed_ordered; NULL: the spatial order and tile_ranges).  Any order of the
+ * tiles is a correct one: the outputs do not depend on it, bit for bit; the records must agree with tile_ranges.  zero_buf / zero_bytes may be NULL / 0. */
 int cugs_rasterize_forward_ordered(int width, int height, const float background_host[3],
                                    const int32_t* tile_ranges, const int32_t* gaussian_indices,
                                    const float* means_2d, const float* cov_2d_inv, const float* rgb,
@@ -273,7 +274,8 @@ int cugs_rasterize_backward_prezeroed(int width, int height, const float backgro
                                       float* dL_dcov_2d_inv, void* stream);
 
 /* cugs_rasterize_backward (prezeroed == 0) or cugs_rasterize_backward_prezeroed (!= 0) with the workgroups handed out in
- * the order tile_order[0 .. tiles) (NULL: the spatial order).  The sums are the same up to the order of the atomic adds. */
+ * the order of the records tile_order[0 .. tiles)[4] (NULL: the spatial order).  The sums are the same up to the order of
+ * the atomic adds. */
 int cugs_rasterize_backward_ordered(int width, int height, const float background_host[3],
                                     const int32_t* tile_ranges, const int32_t* gaussian_indices,
                                     const float* means_2d, const float* cov_2d_inv, const float* rgb,

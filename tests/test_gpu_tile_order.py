@@ -27,8 +27,9 @@ def _bucket(length):
     (50, 1920, 1080, -4.6, None),               # nearly every tile empty
     (20000, 333, 211, -3.5, (0.5, 0.02)),
 ])
-def test_tile_order_is_a_permutation_longest_first(pkg, dev, n, w, h, mu_s, cluster):
+def test_tile_order_is_a_permutation_longest_first(pkg, dev, monkeypatch, n, w, h, mu_s, cluster):
     R = pkg.rasterizer
+    monkeypatch.setattr(R, "TILE_ORDER_MIN_PAIRS", 0)              # render() makes the order for large frames only
     arrays = pkg.scene.make_gaussians(n, w, h, sh_degree=1, seed=n, mu_s=mu_s, cluster=cluster)
     cam = pkg.scene.make_camera(w, h)
     model = pkg.scene.to_model(arrays, dev)
@@ -37,15 +38,21 @@ def test_tile_order_is_a_permutation_longest_first(pkg, dev, n, w, h, mu_s, clus
     tiles = outs[0].tile_ranges.shape[0]
     for out in outs:
         lens = np_(out.tile_ranges[:, 1] - out.tile_ranges[:, 0]).astype(np.int64)
-        for order in (np_(out.tile_order), np_(R.tile_order_of(out.tile_ranges, w, h))):
-            assert sorted(order.tolist()) == list(range(tiles))
+        tr = np_(out.tile_ranges).astype(np.int64)
+        for rec in (np_(out.tile_order), np_(R.tile_order_of(out.tile_ranges, w, h))):
+            order = rec[:, 0]
+            assert rec.shape == (tiles, 4) and sorted(order.tolist()) == list(range(tiles))
             b = np.array([_bucket(int(x)) for x in lens[order]])
             assert np.all(np.diff(b) >= 0)                         # class by class, longest first
+            full = lens[order] > 0                                 # each record carries its tile's range ({t, 0, 0} if empty)
+            assert np.array_equal(rec[full, 1], tr[order[full], 0]) and np.array_equal(rec[full, 2], tr[order[full], 1])
+            assert not rec[~full, 1:3].any() and not rec[:, 3].any()
     assert torch.equal(outs[1].color, outs[0].color) and torch.equal(outs[2].n_contrib, outs[0].n_contrib)
 
 
-def test_blends_do_not_depend_on_the_order(pkg, dev):
+def test_blends_do_not_depend_on_the_order(pkg, dev, monkeypatch):
     R = pkg.rasterizer
+    monkeypatch.setattr(R, "TILE_ORDER_MIN_PAIRS", 0)
     n, w, h = 30000, 640, 360
     arrays = pkg.scene.make_gaussians(n, w, h, sh_degree=2, seed=5, mu_s=-3.8, cluster=(0.7, 0.05))
     cam = pkg.scene.make_camera(w, h)
@@ -55,8 +62,11 @@ def test_blends_do_not_depend_on_the_order(pkg, dev):
     tiles = out.tile_ranges.shape[0]
     g = torch.from_numpy(pkg.scene.make_dl_dcolor(w, h)).to(dev)
     gen = torch.Generator().manual_seed(3)
-    orders = [None, out.tile_order, torch.randperm(tiles, generator=gen).to(torch.int32).to(dev),
-              torch.arange(tiles - 1, -1, -1, dtype=torch.int32, device=dev)]
+    def records(perm):                                             # {tile, first pair, one past the last pair, 0}
+        perm = perm.to(dev).long()
+        return torch.cat([perm[:, None].int(), out.tile_ranges[perm], torch.zeros((tiles, 1), dtype=torch.int32, device=dev)],
+                         dim=1).contiguous()
+    orders = [None, out.tile_order, records(torch.randperm(tiles, generator=gen)), records(torch.arange(tiles - 1, -1, -1))]
     ref_f = ref_b = None
     for order in orders:
         accum = torch.empty((n, pkg._lib.GRAD_STRIDE), dtype=torch.float32, device=dev)
@@ -74,7 +84,7 @@ def test_blends_do_not_depend_on_the_order(pkg, dev):
             assert max_err_over_max(np_(getattr(b, name)), np_(getattr(ref_b, name))) <= 1e-5, name
     with pytest.raises(Exception):
         R.rasterize_forward(out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges, out.gaussian_indices,
-                            w, h, st.background, packed=out.packed, tile_order=orders[2][:-1].contiguous())
+                            w, h, st.background, packed=out.packed, tile_order=orders[2][:-1].contiguous())   # a record short
 
 
 def test_render_is_the_same_with_and_without_the_order(pkg, orc, dev, monkeypatch):
@@ -88,6 +98,7 @@ def test_render_is_the_same_with_and_without_the_order(pkg, orc, dev, monkeypatc
     g = pkg.scene.make_dl_dcolor(w, h)
     ref = oracle_forward(orc, arrays, cam, degree=3)
     refb = oracle_backward(orc, g, ref, arrays, cam)
+    monkeypatch.setattr(R, "TILE_ORDER_MIN_PAIRS", 0)
     for on in (True, False):
         monkeypatch.setattr(R, "TILE_ORDER", on)
         for _ in range(2):

@@ -72,7 +72,14 @@ for spec in (sys.argv[1:] or ["uniform", "0.8:0.1", "0.5:0.02"]):
         mine = SHIPPED[x::8]
         per[x::8] = mine[np.argsort(-lens[mine], kind="stable")]
     orders["lpt-per-xcd"] = per
-    orders["library"] = R.tile_order_of(out.tile_ranges, wl.width, wl.height).cpu().numpy().astype(np.int64)
+    orders["library"] = R.tile_order_of(out.tile_ranges, wl.width, wl.height)[:, 0].cpu().numpy().astype(np.int64)
+    tr_host = out.tile_ranges.cpu().numpy()
+
+    def records(perm):                            # {tile, first pair, one past the last pair, 0}
+        rec = np.zeros((tiles, 4), dtype=np.int32)
+        rec[:, 0] = perm
+        rec[:, 1:3] = tr_host[perm]
+        return torch.from_numpy(rec).to(dev)
     cur = {"order": None}
     fwd = lambda: R.rasterize_forward(out.means_2d, out.cov_2d_inv, out.rgb, out.opacities_act, out.tile_ranges,
                                       out.gaussian_indices, wl.width, wl.height, st.background, packed=out.packed,
@@ -84,7 +91,7 @@ for spec in (sys.argv[1:] or ["uniform", "0.8:0.1", "0.5:0.02"]):
     print(f"{spec}: pairs {out.total_pairs}, tile lists mean {lens.mean():.0f} max {lens.max()}", flush=True)
     for rnd in range(2):
         for name, perm in orders.items():
-            cur["order"] = None if perm is None else torch.from_numpy(perm.astype(np.int32)).to(dev)
+            cur["order"] = None if perm is None else records(perm)
             torch.cuda.synchronize()
             assert torch.equal(fwd().color, ref_color)
             tf, tb = time_kernel(fwd), time_kernel(bwd)
