@@ -62,6 +62,8 @@ def main():
     extra_mode = len(sys.argv) > 3 and sys.argv[3] == "extra"
     only = int(os.environ.get("FUZZ_ONLY", "-1"))             # replay ONE case of a sweep (same draws), with a report
     pkg, orc = ge.load_package(), ge.load_oracle()
+    pkg.rasterizer.TILE_ORDER_MIN_PAIRS = 0       # the blends in longest-list-first order on every scene (render() asks for it
+                                                  # from 2 M pairs on only)
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
     worst, ill = 0.0, 0
