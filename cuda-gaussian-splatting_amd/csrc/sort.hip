@@ -76,6 +76,7 @@ struct SortWsN {
     uint32_t* bin_ttot;          // [tiles] pairs per tile
     uint32_t* bin_tpre;          // [tiles] pairs of the earlier tiles of the tile's 64-tile chunk
     uint32_t* bin_csum;          // [chunks] pairs per 64-tile chunk
+    uint32_t* bin_win;           // [BIN_WINDOWS_MAX] pairs per window of the scatter's workgroups (k_bin_scan; cleared by k_bin_count)
     uint32_t* bin_tbase;         // [tiles + 1] first real pair of each tile; [tiles] = pair total
     size_t bytes;
 };
@@ -119,6 +120,7 @@ inline uint32_t sup_used(uint32_t nblk, int rdx, uint32_t grp) { return (uint32_
 // Direct binning (k_bin_count / k_bin_scan / k_bin_scatter further down): table geometry, needed by the workspace carving.
 constexpr int BIN_TILES_CAP = 10240;              // tiles of the image (k_bin_count's LDS row)
 constexpr uint32_t BIN_GROUP = 4096u, BIN_ROWS_MAX = 512u;
+constexpr uint32_t BIN_WINDOWS_MAX = 64u;         // windows (8 tile rows x <= 64 tile columns) whose weights order the scatter's workgroups
 // Gaussians per table row (and per workgroup of k_bin_count): measured best of 2048 ... 16384 at 1 M Gaussians.  The route is
 // taken for up to BIN_ROWS_MAX rows = 2 M Gaussians: at 6 M (40 M pairs) it ties with the radix passes (0.83 ms both,
 // profiles/r03_s_direct_binning.log), which stay in charge there.
@@ -166,6 +168,7 @@ SortWsN carve_n(void* base, int64_t n) {
     w.bin_ttot = c.take<uint32_t>(BIN_TILES_CAP);
     w.bin_tpre = c.take<uint32_t>(BIN_TILES_CAP);
     w.bin_csum = c.take<uint32_t>(BIN_TILES_CAP / 64 + 4);
+    w.bin_win = c.take<uint32_t>(BIN_WINDOWS_MAX);
     w.bin_tbase = c.take<uint32_t>(BIN_TILES_CAP + 1);
     w.bytes = c.off;
     return w;
@@ -1005,6 +1008,13 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t tiles, const int32
 // ------------------------------------------------------------------------------------
 constexpr int BIN_WAVES = 16, BIN_NT = BIN_WAVES * CUGS_WAVE;
 constexpr int BIN_T_MAX = BIN_TILES_CAP;
+// The scatter's workgroups: up to 8 horizontally adjacent blocks of 8 x 8 tiles, evenly filled (15 block columns: 8 + 7)
+inline uint32_t bin_window_groups(int ntx) { const uint32_t nbx = ((uint32_t)ntx + 7u) / 8u; return (nbx + 7u) / 8u; }
+inline uint32_t bin_window_cols(int ntx) {       // tile columns per window
+    const uint32_t nbx = ((uint32_t)ntx + 7u) / 8u, gxs = bin_window_groups(ntx);
+    return ((nbx + gxs - 1u) / gxs) * 8u;
+}
+inline uint32_t bin_windows(int ntx, int nty) { return (((uint32_t)nty + 7u) / 8u) * bin_window_groups(ntx); }
 inline bool bin_route(int ntx, int nty) {
     return cugs_prect_packable(ntx, nty) && ntx * nty <= BIN_T_MAX;
 }
@@ -1019,8 +1029,10 @@ constexpr int BIN_D_MAX = BIN_T_MAX + 2 * CUGS_PRECT_MAX_TILES + 2;   // (ntx + 
 __global__ __launch_bounds__(BIN_NT) void k_bin_count(uint32_t n, uint32_t group, const uint32_t* __restrict__ order,
                                                       const int4* __restrict__ rect, const uint32_t* __restrict__ prect_in,
                                                       uint32_t* __restrict__ prect_out, uint32_t ntx, uint32_t nty,
-                                                      uint32_t* __restrict__ table, uint32_t* __restrict__ zero_pairs) {
+                                                      uint32_t* __restrict__ table, uint32_t* __restrict__ zero_pairs,
+                                                      uint32_t* __restrict__ win) {
     __shared__ int32_t s_d[BIN_D_MAX];
+    if (blockIdx.x == 0 && threadIdx.x < BIN_WINDOWS_MAX) win[threadIdx.x] = 0u;      // k_bin_scan adds the windows' pairs up
     __shared__ int32_t s_part[8][128];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t w2 = ntx + 1u, cells = w2 * (nty + 1u);
@@ -1092,8 +1104,11 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_count(uint32_t n, uint32_t group
 __global__ __launch_bounds__(BIN_NT) void k_bin_scan(uint32_t rows, uint32_t tiles, uint32_t* __restrict__ table,
                                                      uint32_t* __restrict__ ttot, uint32_t* __restrict__ tpre,
                                                      uint32_t* __restrict__ csum, uint32_t* __restrict__ q12,
-                                                     uint32_t* __restrict__ range_flag, uint32_t* __restrict__ snap) {
+                                                     uint32_t* __restrict__ range_flag, uint32_t* __restrict__ snap,
+                                                     uint32_t* __restrict__ win, uint32_t ntx, uint32_t win_cols,
+                                                     uint32_t gxs) {
     __shared__ uint32_t s_seg[BIN_WAVES][CUGS_WAVE];
+    __shared__ uint32_t s_win[BIN_WINDOWS_MAX];                       // touched by wave 0 only
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         snap[0] = q12[0]; q12[1] = q12[0]; q12[0] = 0u;
         snap[1] = *range_flag; *range_flag = 0u;
@@ -1130,6 +1145,21 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scan(uint32_t rows, uint32_t til
         const uint32_t inc = wave_inclusive_scan(v);
         if (t < tiles) { ttot[t] = v; tpre[t] = inc - v; }
         if (tl == 63u) csum[blockIdx.x] = inc;
+        // pairs per WINDOW of the scatter (8 tile rows x win_cols tile columns: one workgroup per group of the depth order):
+        // what the scatter orders its workgroups by (win == NULL: more windows than BIN_WINDOWS_MAX, no ordering)
+        if (win) {                                                    // (kernel-uniform; all of it inside this one wave)
+            s_win[tl] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (v) {
+                const uint32_t ty = t / ntx, tx = t - ty * ntx;
+                atomicAdd(&s_win[(ty >> 3) * gxs + tx / win_cols], v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t mine = s_win[tl];
+            if (mine) atomicAdd(&win[tl], mine);
+        }
     }
 }
 
@@ -1165,7 +1195,8 @@ __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
     const uint32_t* __restrict__ table, const uint32_t* __restrict__ ttot, const uint32_t* __restrict__ tpre,
     const uint32_t* __restrict__ csum, const uint32_t* __restrict__ snap, uint32_t* __restrict__ tbase,
     unsigned long long* __restrict__ total, unsigned long long* __restrict__ total_mapped, uint32_t* __restrict__ out,
-    int32_t* __restrict__ tile_ranges, uint32_t* __restrict__ tile_order, uint32_t ablate) {
+    int32_t* __restrict__ tile_ranges, uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ win,
+    uint32_t ablate) {
     __shared__ uint2 s_cand[BIN_WG_WAVES][BIN_SLICE];                 // {packed rectangle, Gaussian} of the listed records
     __shared__ uint32_t s_cnt[BIN_WG_WAVES];
     __shared__ uint32_t s_run[STAGE ? BIN_WG_WAVES * CUGS_WAVE * BIN_RUN_STRIDE + 4 : 1];   // (+ the read-ahead of the last row's flush)
@@ -1176,8 +1207,13 @@ __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
 #endif
     const uint32_t nt = blockDim.x, nw = nt >> 6, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
     const uint32_t per_group = nby * gxs;
-    const uint32_t blk = blockIdx.x / per_group, rem = blockIdx.x - blk * per_group;
-    const uint32_t by = rem / gxs, gx = rem - by * gxs;
+    // Which (group, window) this workgroup takes.  Balanced views: group-major (the windows of one group side by side:
+    // they read the same records).  When one window holds over twice the mean (a view whose splats cluster: half of every
+    // group's records can fall into ONE 8 x 8 tile block, whose wave then walks them one by one for tens of microseconds):
+    // window-major with the heaviest window first, so that those long workgroups all start at once instead of one per
+    // group all the way to the end of the grid (k_bin_scatter 155 -> 96 us with half of the splats on 2 % of the screen).
+    uint32_t blk = blockIdx.x / per_group, rem = blockIdx.x - blk * per_group;
+    const uint32_t win_mine = (win && lane < per_group) ? win[lane] : 0u;     // pairs of window `lane` (k_bin_scan)
     const uint32_t zero = snap[0];                                    // quirk Q12's (tile 0, Gaussian 0) pairs: the head of tile 0's list
     const bool bad = snap[1] != 0u;                                   // a depth key outside the three-pass range: nothing is valid
     const uint32_t tiles = ntx * nty;
@@ -1207,6 +1243,19 @@ __global__ __launch_bounds__(BIN_WG_WAVES * CUGS_WAVE) void k_bin_scatter(
     }
     const bool fits = !bad && (!predicted || pairs <= pairs_or_cap);
     cpre[0] -= zero; cpre[1] -= zero; cpre[2] -= zero;                // (the Q12 pairs are added to `start` below)
+    // does one window hold over twice the mean?  (one compare and a ballot per wave; `pairs` is the total)
+    if (__ballot((unsigned long long)win_mine * per_group > 2ull * pairs) != 0ull) {     // kernel-uniform
+        uint32_t rank = 0u;                                           // (v_readlane with a scalar lane: no LDS round trips)
+        for (uint32_t w2 = 0; w2 < per_group; ++w2) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)win_mine, (int)w2);
+            rank += (o > win_mine || (o == win_mine && w2 < lane)) ? 1u : 0u;
+        }
+        const uint32_t groups = gridDim.x / per_group;
+        const uint32_t slot = blockIdx.x / groups;
+        blk = blockIdx.x - slot * groups;
+        rem = (uint32_t)__builtin_ctzll(__ballot(lane < per_group && rank == slot));
+    }
+    const uint32_t by = rem / gxs, gx = rem - by * gxs;
 
     const uint32_t bx = gx * nw + wid;
     const bool active = bx < nbx;
@@ -1521,8 +1570,9 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         // blocks of 8 x 8 tiles, one per wave; workgroups of up to 8 horizontally adjacent blocks, evenly filled
         // (15 block columns: 8 + 7).  Launched for capacity 0 too: the kernel publishes the totals and the ranges.
         const uint32_t nbx = ((uint32_t)ntx + BIN_BLK - 1u) / BIN_BLK, nby = ((uint32_t)nty + BIN_BLK - 1u) / BIN_BLK;
-        const uint32_t gxs = (nbx + BIN_WG_WAVES - 1u) / BIN_WG_WAVES;
-        const uint32_t waves = (nbx + gxs - 1u) / gxs;
+        const uint32_t gxs = bin_window_groups(ntx);
+        const uint32_t waves = bin_window_cols(ntx) / BIN_BLK;
+        const uint32_t* const win = bin_windows(ntx, nty) <= BIN_WINDOWS_MAX ? ws.bin_win : nullptr;
 #ifdef CUGS_DEV
         if (hipEvent_t mark = static_cast<hipEvent_t>(g_mark_event.load(std::memory_order_relaxed)))   // tools/late_colour.py
             CUGS_RETURN_IF_HIP(hipEventRecord(mark, st));
@@ -1533,7 +1583,7 @@ int sort_pairs_typed(const SortWsN& ws, const SortWsP& wp, uint32_t un, uint32_t
         hipLaunchKernelGGL(k_bin_scatter<S>, dim3(bin_rows(un) * nby * gxs), dim3(waves * CUGS_WAVE), 0, st, un, bin_group(), nbx, nby, gxs, \
                            up, dev_count != nullptr, order, static_cast<const uint32_t*>(ws.prect[1]), (uint32_t)ntx, (uint32_t)nty,      \
                            ws.bin_table, ws.bin_ttot, ws.bin_tpre, ws.bin_csum, zsnap, ws.bin_tbase, ws.total, total_mapped,             \
-                           reinterpret_cast<uint32_t*>(values_sorted), tile_ranges, tile_order, bin_ablate())
+                           reinterpret_cast<uint32_t*>(values_sorted), tile_ranges, tile_order, win, bin_ablate())
         if (staged) CUGS_LAUNCH_SCATTER(true); else CUGS_LAUNCH_SCATTER(false);
 #undef CUGS_LAUNCH_SCATTER
         CUGS_LAUNCH_CHECK();
@@ -1656,10 +1706,12 @@ int queue_count(const SortWsN& ws, uint32_t un, const float* means_2d, const flo
         uint32_t* const snap = reinterpret_cast<uint32_t*>(ws.total) + 10;   // [0] Q12 pairs, [1] depth range flag
         hipLaunchKernelGGL(k_bin_count, dim3(rows), dim3(BIN_NT), 0, st, un, bin_group(), ws.dval[1], ws.rect[0],
                            riding ? static_cast<const uint32_t*>(ws.prect[1]) : static_cast<const uint32_t*>(nullptr),
-                           riding ? static_cast<uint32_t*>(nullptr) : ws.prect[1], (uint32_t)ntx, (uint32_t)nty, ws.bin_table, q12);
+                           riding ? static_cast<uint32_t*>(nullptr) : ws.prect[1], (uint32_t)ntx, (uint32_t)nty, ws.bin_table, q12,
+                           ws.bin_win);
         CUGS_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_bin_scan, dim3((tiles + CUGS_WAVE - 1) / CUGS_WAVE), dim3(BIN_NT), 0, st, rows, tiles, ws.bin_table,
-                           ws.bin_ttot, ws.bin_tpre, ws.bin_csum, q12, range_flag, snap);
+                           ws.bin_ttot, ws.bin_tpre, ws.bin_csum, q12, range_flag, snap, bin_windows(ntx, nty) <= BIN_WINDOWS_MAX ? ws.bin_win : nullptr,
+                           (uint32_t)ntx, bin_window_cols(ntx), bin_window_groups(ntx));
         CUGS_LAUNCH_CHECK();
         return 0;
     }
