@@ -109,3 +109,28 @@ def test_render_is_the_same_with_and_without_the_order(pkg, orc, dev, monkeypatc
         grads = pkg.render_backward(torch.from_numpy(g).to(dev), out, model, cam, st)
         for name in GRAD_NAMES:
             assert max_err_over_max(np_(getattr(grads, name)), refb[name]) <= 1e-4, (on, name)
+
+
+@pytest.mark.parametrize("cluster", [(0.5, 0.02), (0.9, 0.01)])
+def test_clustered_view_through_the_window_major_scatter(pkg, orc, dev, cluster):
+    """Half (or nine tenths) of the splats on a fiftieth (a hundredth) of a 1080p screen: one of the eighteen windows of the
+    binned sort's scatter holds many times the mean, its grid is read window-major with the heaviest window first - and
+    the pairs, their order, the ranges and the image are still the oracle's, frame after frame."""
+    n, w, h = 40000, 1920, 1080
+    arrays = pkg.scene.make_gaussians(n, w, h, sh_degree=0, seed=31, mu_s=-4.2, cluster=cluster)
+    cam = pkg.scene.make_camera(w, h)
+    model = pkg.scene.to_model(arrays, dev)
+    st = pkg.RenderSettings(active_sh_degree=0)
+    K = cam.intrinsics
+    ref = orc.render(arrays, cam.rotation, cam.translation, K.fx, K.fy, K.cx, K.cy, w, h, active_degree=0,
+                     threads=orc.host_threads())
+    lens = (ref["tile_ranges"][:, 1] - ref["tile_ranges"][:, 0]).reshape(68, 120)
+    windows = [lens[8 * by:8 * by + 8, 64 * gx:64 * gx + 64].sum() for by in range(9) for gx in range(2)]
+    assert max(windows) * len(windows) > 2 * sum(windows)          # the rule of k_bin_scatter is met
+    for attempt in range(3):                                       # exact sort, then twice the keyed, binned one
+        out = pkg.render(model, cam, st)
+        assert out.total_pairs == ref["total_pairs"], attempt
+        assert np.array_equal(np_(out.gaussian_indices), ref["values"]), attempt
+        assert np.array_equal(np_(out.tile_ranges), ref["tile_ranges"]), attempt
+        assert np.array_equal(np_(out.n_contrib), ref["n_contrib"]), attempt
+        assert np.array_equal(np_(out.color).view(np.uint32), ref["color"].view(np.uint32)), attempt
