@@ -1,7 +1,7 @@
 """Randomised parity sweep (not part of the test suite): many small random scenes - sizes, image shapes, SH degrees,
 splat scales from sub-pixel to screen-filling, views, backgrounds, scale modifiers - rendered and differentiated on
 the GPU and by the oracle.  Integers, order, tile ranges, n_contrib and the image must be bit-equal, gradients within
-1e-4 of each tensor's scale.    python tools/fuzz_parity.py [cases] [seed] [dense|extra|cluster|dense-cluster]
+1e-4 of each tensor's scale.    python tools/fuzz_parity.py [cases] [seed] [dense|extra|cluster|dense-cluster|wide]
 FUZZ_ONLY=<k> replays case k of a sweep with a per-tensor report."""
 import os
 import sys
@@ -62,6 +62,7 @@ def main():
     extra_mode = len(sys.argv) > 3 and sys.argv[3] == "extra"
     cluster_mode = len(sys.argv) > 3 and sys.argv[3] in ("cluster", "dense-cluster")
     dense = dense or (len(sys.argv) > 3 and sys.argv[3] == "dense-cluster")
+    wide_mode = len(sys.argv) > 3 and sys.argv[3] == "wide"   # over 127 tiles along one axis: the sort's radix pair route
     only = int(os.environ.get("FUZZ_ONLY", "-1"))             # replay ONE case of a sweep (same draws), with a report
     pkg, orc = ge.load_package(), ge.load_oracle()
     if not os.environ.get("FUZZ_NO_ORDER"):     # the blends in longest-list-first order on every scene (render() asks for
@@ -79,6 +80,13 @@ def main():
             n = int(rng.choice([5000, 12000, 25000]))
             w, h = [(640, 360), (1000, 400), (1280, 720), (517, 389)][int(rng.integers(0, 4))]
             mu_s = float(rng.choice([-3.6, -3.2, -2.8]))
+        if wide_mode:
+            wg = np.random.default_rng([seed, k, 3])
+            w = int(wg.choice([2033, 2048, 2049, 3000, 4100]))
+            h = int(wg.choice([9, 16, 40, 100]))
+            if wg.random() < 0.5:
+                w, h = h, w
+            n = int(wg.choice([100, 3000, 8000, 20000]))
         view = int(rng.integers(0, 6))
         bg = tuple(float(x) for x in rng.random(3))
         scale_mod = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
