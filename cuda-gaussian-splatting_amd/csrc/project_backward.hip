@@ -80,6 +80,29 @@ __device__ __forceinline__ void load_sh_rows(const float* __restrict__ sh, int64
     }
 }
 
+// The gradient rows of a workgroup from their FACTORS: row r = gated[r][ch] * Y[r][k] (sh_backward.cu:99-108) - the tile
+// holds 20 floats per Gaussian (the 16 basis values, the three gated colour gradients, one pad) instead of the 3C
+// products, 20 KB instead of 50 KB per workgroup, so EIGHT workgroups share a CU where three did, and the products are
+// formed by the thread that stores them (the same single fp32 multiplication, so bit for bit the same rows).
+constexpr int SH_FACTOR_ROW = 20;
+__device__ __forceinline__ void store_sh_rows_from_factors(float* __restrict__ dst_base, int64_t base, int count, int num_active,
+                                                           const float* s_fac) {
+    constexpr int C = 16, ROW4 = 3 * C / 4;                          // 12 float4 per Gaussian
+    float4* dst4 = reinterpret_cast<float4*>(dst_base + base * (3 * C));
+    const int total4 = count * ROW4;
+#pragma unroll
+    for (int i = 0; i < ROW4; ++i) {
+        const int e4 = (int)threadIdx.x + i * CUGS_BLOCK;
+        if (e4 < total4) {
+            const int r = e4 / ROW4, j = e4 - r * ROW4, ch = j >> 2, k = (j & 3) * 4;
+            const float4 y = *reinterpret_cast<const float4*>(s_fac + r * SH_FACTOR_ROW + k);
+            const float g = s_fac[r * SH_FACTOR_ROW + 16 + ch];
+            cugs_stnt(dst4 + e4, make_float4(k + 0 < num_active ? g * y.x : 0.0f, k + 1 < num_active ? g * y.y : 0.0f,
+                                             k + 2 < num_active ? g * y.z : 0.0f, k + 3 < num_active ? g * y.w : 0.0f));
+        }
+    }
+}
+
 template <int C, bool ALIGNED>
 __device__ __forceinline__ void store_sh_rows(float* __restrict__ dst_base, int64_t base, int count,
                                               const float* s_sh) {
@@ -252,11 +275,14 @@ struct PBPtrs {
 // ADAM: instead of writing the five parameter gradients, apply the Adam update to this Gaussian's parameters in
 // the same pass (every thread touches only its own Gaussian; the SH block goes through the LDS tile): 236 B/Gaussian
 // of gradient writes and as many reads by a separate optimizer launch disappear (472 of 2020 B at degree 3).
-template <int C, bool ALIGNED, bool ADAM>
+// FACTORS (C == 16, aligned rows, the gate bits given, no fused optimizer step): the LDS tile holds the factors of the
+// gradient rows instead of the rows (store_sh_rows_from_factors).
+template <int C, bool ALIGNED, bool ADAM, bool FACTORS = false>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int degree, CamArgs cam, PBPtrs p,
                                                                 AdamFusedArgs adam) {
-    constexpr int LROW = ShTile<C>::LROW;
-    __shared__ float s_sh[CUGS_BLOCK * LROW];
+    static_assert(!FACTORS || (C == 16 && ALIGNED && !ADAM), "factor tile: degree-3 storage, 16-byte rows, plain gradients");
+    constexpr int LROW = FACTORS ? SH_FACTOR_ROW : ShTile<C>::LROW;
+    __shared__ __attribute__((aligned(16))) float s_sh[CUGS_BLOCK * LROW];
     const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
     const int count = (int)min((int64_t)CUGS_BLOCK, n - base);
     const int64_t idx = base + threadIdx.x;
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     // parameters are streamed (non-temporal) unless the fused optimizer step reads them again further down
     auto ldp = [](const float* q_) { return ADAM ? *q_ : cugs_ldnt(q_); };
 
-    const bool gate_from_sh = (p.colour_gate == nullptr);      // kernel-uniform
+    const bool gate_from_sh = !FACTORS && (p.colour_gate == nullptr);      // kernel-uniform
     if (gate_from_sh) {
         load_sh_rows<C, ALIGNED>(p.sh, base, count, s_sh);
         __syncthreads();
@@ -278,6 +304,17 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     Sym2 g_inv{0.0f, 0.0f, 0.0f};
     GradMoments mom{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};            // grad_accum rows carry moments (raster_backward.hip)
     const bool from_rows = (p.grad_accum != nullptr);         // kernel-uniform
+    // FACTORS: the geometry inputs are requested here, with everything else the thread reads, so that the kernel pays one
+    // memory round trip and not a second one behind the gradient rows (same values, same arithmetic further down)
+    float in_scl[3] = {0.0f, 0.0f, 0.0f}, in_opa = 0.0f;
+    float4 in_q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int in_radius = 0;
+    if (FACTORS && live) {
+        in_radius = p.radii[idx];
+        in_scl[0] = ldp(p.scales + idx * 3 + 0); in_scl[1] = ldp(p.scales + idx * 3 + 1); in_scl[2] = ldp(p.scales + idx * 3 + 2);
+        in_q = cugs_ldnt(reinterpret_cast<const float4*>(p.rotations) + idx);
+        in_opa = ldp(p.opacities + idx);
+    }
     if (live) {
         pos = V3{ldp(p.positions + idx * 3 + 0), ldp(p.positions + idx * 3 + 1), ldp(p.positions + idx * 3 + 2)};
         float g_rgb[3];
@@ -304,7 +341,18 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     }
     if (gate_from_sh) __syncthreads();                         // coefficients consumed; reuse the tile
 
-    if (ADAM || p.d_sh) {                                      // kernel-uniform
+    if (FACTORS) {
+        if (live) {
+            float4* row = reinterpret_cast<float4*>(s_sh + threadIdx.x * SH_FACTOR_ROW);
+            row[0] = make_float4(Y[0], Y[1], Y[2], Y[3]);
+            row[1] = make_float4(Y[4], Y[5], Y[6], Y[7]);
+            row[2] = make_float4(Y[8], Y[9], Y[10], Y[11]);
+            row[3] = make_float4(Y[12], Y[13], Y[14], Y[15]);
+            row[4] = make_float4(gated[0], gated[1], gated[2], 0.0f);
+        }
+        __syncthreads();
+        store_sh_rows_from_factors(p.d_sh, base, count, num_active, s_sh);
+    } else if (ADAM || p.d_sh) {                               // kernel-uniform
         if (live) {
             float* row = s_sh + threadIdx.x * LROW;
 #pragma unroll
@@ -322,12 +370,15 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     V3 d_pos{0.0f, 0.0f, 0.0f}, d_log{0.0f, 0.0f, 0.0f};
     float4 d_q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float d_logit = 0.0f;
-    if (p.radii[idx] > 0) {                                    // projection_backward.cu:48
+    if ((FACTORS ? in_radius : p.radii[idx]) > 0) {            // projection_backward.cu:48
         const M3 W = view_rotation(cam);
         const V3 t = to_camera(cam, W, pos);
-        const V3 s{cugs_expf(ldp(p.scales + idx * 3 + 0) + cam.log_mod), cugs_expf(ldp(p.scales + idx * 3 + 1) + cam.log_mod),
-                   cugs_expf(ldp(p.scales + idx * 3 + 2) + cam.log_mod)};
-        const float4 q = ALIGNED ? (ADAM ? reinterpret_cast<const float4*>(p.rotations)[idx]
+        if (!FACTORS) {
+            in_scl[0] = ldp(p.scales + idx * 3 + 0); in_scl[1] = ldp(p.scales + idx * 3 + 1); in_scl[2] = ldp(p.scales + idx * 3 + 2);
+        }
+        const V3 s{cugs_expf(in_scl[0] + cam.log_mod), cugs_expf(in_scl[1] + cam.log_mod), cugs_expf(in_scl[2] + cam.log_mod)};
+        const float4 q = FACTORS ? in_q
+                       : ALIGNED ? (ADAM ? reinterpret_cast<const float4*>(p.rotations)[idx]
                                          : cugs_ldnt(reinterpret_cast<const float4*>(p.rotations) + idx))
                                  : make_float4(p.rotations[idx * 4 + 0], p.rotations[idx * 4 + 1],
                                                p.rotations[idx * 4 + 2], p.rotations[idx * 4 + 3]);
@@ -365,7 +416,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
             d_pos.y = W.m01 * dt.x + W.m11 * dt.y + W.m21 * dt.z;
             d_pos.z = W.m02 * dt.x + W.m12 * dt.y + W.m22 * dt.z;
 
-            const float sig = cugs_sigmoidf(ldp(p.opacities + idx));
+            const float sig = cugs_sigmoidf(FACTORS ? in_opa : ldp(p.opacities + idx));
             d_logit = g_opa * sig * (1.0f - sig);
         }
     }
@@ -558,6 +609,13 @@ int launch_pb(int64_t n, int degree, const CamArgs& cam, const PBPtrs& p, bool a
         else
             hipLaunchKernelGGL((k_project_backward<C, false, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p, *adam);
     } else if (aligned) {
+        if constexpr (C == 16) {
+            if (p.colour_gate && p.d_sh) {
+                hipLaunchKernelGGL((k_project_backward<C, true, false, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p, none);
+                CUGS_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         hipLaunchKernelGGL((k_project_backward<C, true, false>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p, none);
     } else {
         hipLaunchKernelGGL((k_project_backward<C, false, false>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p, none);
