@@ -551,6 +551,44 @@ def test_project_backward_stage_parity(pkg, orc, dev):
     assert max_rel_err(np_(pb.dL_dsh_coeffs), want_sh) <= 1e-6
 
 
+@pytest.mark.parametrize("n,active", [(8000, 3), (257, 3), (5003, 1), (64, 0)])
+def test_project_backward_factor_tile_equals_the_row_tile(pkg, orc, dev, n, active):
+    """With the projection's gate bits and degree-3 storage the kernel keeps the FACTORS of the SH gradient rows in LDS
+    (16 basis values + 3 gated colour gradients per Gaussian) and the storing thread multiplies; without
+    the bits it assembles the rows themselves in the 50 KB tile.  Same products, same selects: every output bit for bit
+    the same - ragged last workgroup, fewer active coefficients than stored ones (zeros beyond) and the geometry
+    gradients, whose inputs the factor route requests earlier, included - and both the oracle's."""
+    w, h = 320, 200
+    arrays, cam = _scene(pkg, n, w, h, 3, seed=100 + n, mu_s=-3.6, view=1)
+    ref = oracle_forward(orc, arrays, cam, degree=active)
+    rng = np.random.default_rng(n)
+    gm = rng.standard_normal((n, 2)).astype(np.float32)
+    gc = rng.standard_normal((n, 3)).astype(np.float32)
+    gr = rng.standard_normal((n, 3)).astype(np.float32)
+    go = rng.standard_normal(n).astype(np.float32)
+    model = pkg.scene.to_model(arrays, dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    proj = pkg.project_gaussians(model.positions, model.rotations, model.scales, model.opacities, model.sh_coeffs, cam, active)
+    assert proj.colour_gate is not None
+    args = (t(gm), t(gc), t(gr), t(go), model.positions, model.rotations, model.scales, model.opacities,
+            model.sh_coeffs, t(ref["radii"]), cam, active)
+    rows = pkg.project_backward(*args)                                    # gate recomputed, rows in the tile
+    fac = pkg.project_backward(*args, colour_gate=proj.colour_gate)       # gate bits given: the factor tile
+    for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs"):
+        a, b = np_(getattr(rows, name)), np_(getattr(fac, name))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+    want_sh = orc.sh_backward(active, arrays["sh_coeffs"], ref["dirs"], gr)
+    got_sh = np_(fac.dL_dsh_coeffs)
+    assert max_rel_err(got_sh, want_sh) <= 1e-6
+    assert not got_sh[:, :, (active + 1) ** 2:].any()
+    K = cam.intrinsics
+    want = orc.project_backward(arrays["positions"], arrays["rotations"], arrays["scales"], arrays["opacities"],
+                                ref["view"], K.fx, K.fy, K.cx, K.cy, 1.0, ref["radii"], gm, gc, go)
+    for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities"):
+        got = np_(getattr(fac, name)).reshape(want[name].shape)
+        assert np.array_equal(got.view(np.uint32), want[name].view(np.uint32)), name
+
+
 @pytest.mark.parametrize("deg,c", [(0, 1), (1, 4), (2, 9), (3, 16), (1, 16), (0, 9)])
 def test_sh_forward_backward_parity(pkg, orc, dev, deg, c):
     """evaluate_sh_cuda / evaluate_sh_backward_cuda; the reference's bar is 1e-4 (test_sh.cpp:161-216)."""
