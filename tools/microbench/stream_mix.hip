@@ -98,6 +98,10 @@ int main() {
         run<4, 8, false, 4>("4 + 8, 4 chunks per workgroup", in, out, pieces, e0, e1);
         run<4, 8, true, 4>("4 + 8, nt, 4 chunks per workgroup", in, out, pieces, e0, e1);
         run<4, 8, true, 8>("4 + 8, nt, 8 chunks per workgroup", in, out, pieces, e0, e1);
+        run<8, 4, false, 1>("8 loads + 4 stores", in, out, pieces, e0, e1);          // the forward projection's mix
+        run<8, 4, true, 1>("8 loads + 4 stores, non-temporal", in, out, pieces, e0, e1);
+        run<8, 4, true, 2>("8 + 4, nt, 2 chunks per workgroup", in, out, pieces, e0, e1);
+        run<8, 4, true, 4>("8 + 4, nt, 4 chunks per workgroup", in, out, pieces, e0, e1);
     }
     return 0;
 }
