@@ -276,7 +276,7 @@ struct PBPtrs {
 // the same pass (every thread touches only its own Gaussian; the SH block goes through the LDS tile): 236 B/Gaussian
 // of gradient writes and as many reads by a separate optimizer launch disappear (472 of 2020 B at degree 3).
 // FACTORS (C == 16, aligned rows, the gate bits given, no fused optimizer step): the LDS tile holds the factors of the
-// gradient rows instead of the rows (store_sh_rows_from_factors).
+// gradient rows instead of the rows (store_sh_rows_from_factors); also the route without SH gradient rows at all.
 template <int C, bool ALIGNED, bool ADAM, bool FACTORS = false>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int degree, CamArgs cam, PBPtrs p,
                                                                 AdamFusedArgs adam) {
@@ -342,6 +342,10 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     if (gate_from_sh) __syncthreads();                         // coefficients consumed; reuse the tile
 
     if (FACTORS) {
+        if (p.d_sh == nullptr) {
+            // kernel-uniform: no SH gradient asked for (the data-parallel exchange builds it from the gathered colour
+            // gradients, cugs_sh_backward_views) - nothing goes through the tile
+        } else {
         if (live) {
             float4* row = reinterpret_cast<float4*>(s_sh + threadIdx.x * SH_FACTOR_ROW);
             row[0] = make_float4(Y[0], Y[1], Y[2], Y[3]);
@@ -352,6 +356,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
         }
         __syncthreads();
         store_sh_rows_from_factors(p.d_sh, base, count, num_active, s_sh);
+        }
     } else if (ADAM || p.d_sh) {                               // kernel-uniform
         if (live) {
             float* row = s_sh + threadIdx.x * LROW;
@@ -610,7 +615,7 @@ int launch_pb(int64_t n, int degree, const CamArgs& cam, const PBPtrs& p, bool a
             hipLaunchKernelGGL((k_project_backward<C, false, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p, *adam);
     } else if (aligned) {
         if constexpr (C == 16) {
-            if (p.colour_gate && p.d_sh) {
+            if (p.colour_gate) {
                 hipLaunchKernelGGL((k_project_backward<C, true, false, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p, none);
                 CUGS_LAUNCH_CHECK();
                 return 0;

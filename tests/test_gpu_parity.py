@@ -577,6 +577,10 @@ def test_project_backward_factor_tile_equals_the_row_tile(pkg, orc, dev, n, acti
     for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities", "dL_dsh_coeffs"):
         a, b = np_(getattr(rows, name)), np_(getattr(fac, name))
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+    bare = pkg.project_backward(*args, colour_gate=proj.colour_gate, skip_sh_grad=True)   # the data-parallel route: no rows
+    assert bare.dL_dsh_coeffs is None
+    for name in ("dL_dpositions", "dL_drotations", "dL_dscales", "dL_dopacities"):
+        assert torch.equal(getattr(bare, name), getattr(fac, name)), name
     want_sh = orc.sh_backward(active, arrays["sh_coeffs"], ref["dirs"], gr)
     got_sh = np_(fac.dL_dsh_coeffs)
     assert max_rel_err(got_sh, want_sh) <= 1e-6
