@@ -82,8 +82,9 @@ __device__ __forceinline__ void load_sh_rows(const float* __restrict__ sh, int64
 
 // The gradient rows of a workgroup from their FACTORS: row r = gated[r][ch] * Y[r][k] (sh_backward.cu:99-108) - the tile
 // holds 20 floats per Gaussian (the 16 basis values, the three gated colour gradients, one pad) instead of the 3C
-// products, 20 KB instead of 50 KB per workgroup, so EIGHT workgroups share a CU where three did, and the products are
-// formed by the thread that stores them (the same single fp32 multiplication, so bit for bit the same rows).
+// products, 20 KB instead of 50 KB per workgroup, so FIVE workgroups share a CU where three did (the kernel's 94 VGPRs
+// bound it now), and the products are formed by the thread that stores them (the same single fp32 multiplication, so bit
+// for bit the same rows).  DESIGN.md 4.6.
 constexpr int SH_FACTOR_ROW = 20;
 __device__ __forceinline__ void store_sh_rows_from_factors(float* __restrict__ dst_base, int64_t base, int count, int num_active,
                                                            const float* s_fac) {
@@ -342,20 +343,19 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     if (gate_from_sh) __syncthreads();                         // coefficients consumed; reuse the tile
 
     if (FACTORS) {
-        if (p.d_sh == nullptr) {
-            // kernel-uniform: no SH gradient asked for (the data-parallel exchange builds it from the gathered colour
-            // gradients, cugs_sh_backward_views) - nothing goes through the tile
-        } else {
-        if (live) {
-            float4* row = reinterpret_cast<float4*>(s_sh + threadIdx.x * SH_FACTOR_ROW);
-            row[0] = make_float4(Y[0], Y[1], Y[2], Y[3]);
-            row[1] = make_float4(Y[4], Y[5], Y[6], Y[7]);
-            row[2] = make_float4(Y[8], Y[9], Y[10], Y[11]);
-            row[3] = make_float4(Y[12], Y[13], Y[14], Y[15]);
-            row[4] = make_float4(gated[0], gated[1], gated[2], 0.0f);
-        }
-        __syncthreads();
-        store_sh_rows_from_factors(p.d_sh, base, count, num_active, s_sh);
+        // kernel-uniform: without dL/dsh (the data-parallel exchange builds it from the gathered colour gradients,
+        // cugs_sh_backward_views) nothing goes through the tile
+        if (p.d_sh) {
+            if (live) {
+                float4* row = reinterpret_cast<float4*>(s_sh + threadIdx.x * SH_FACTOR_ROW);
+                row[0] = make_float4(Y[0], Y[1], Y[2], Y[3]);
+                row[1] = make_float4(Y[4], Y[5], Y[6], Y[7]);
+                row[2] = make_float4(Y[8], Y[9], Y[10], Y[11]);
+                row[3] = make_float4(Y[12], Y[13], Y[14], Y[15]);
+                row[4] = make_float4(gated[0], gated[1], gated[2], 0.0f);
+            }
+            __syncthreads();
+            store_sh_rows_from_factors(p.d_sh, base, count, num_active, s_sh);
         }
     } else if (ADAM || p.d_sh) {                               // kernel-uniform
         if (live) {
