@@ -186,6 +186,42 @@ __device__ __forceinline__ void adam_sh_rows(float* __restrict__ param, float* _
     }
 }
 
+// adam_sh_rows with the gradient formed from the factor tile (store_sh_rows_from_factors): the same products, the same
+// update, in batches of four 16-byte pieces per thread so that a workgroup's 36 loads per thread are not twelve
+// dependent round trips.
+__device__ __forceinline__ void adam_sh_rows_from_factors(float* __restrict__ param, float* __restrict__ mom, float* __restrict__ var,
+                                                          int64_t base, int count, int num_active, const float* s_fac,
+                                                          float lr, const AdamFusedArgs& h) {
+    constexpr int C = 16, ROW4 = 3 * C / 4, BATCH = 4;
+    float4* P = reinterpret_cast<float4*>(param + base * (3 * C));
+    float4* M = reinterpret_cast<float4*>(mom + base * (3 * C));
+    float4* V = reinterpret_cast<float4*>(var + base * (3 * C));
+    const int total4 = count * ROW4;
+#pragma unroll
+    for (int b = 0; b < ROW4; b += BATCH) {
+        float4 pp[BATCH], mm[BATCH], vv[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e4 = min((int)threadIdx.x + (b + u) * CUGS_BLOCK, total4 - 1);      // clamped: the loads stay together
+            pp[u] = cugs_ldnt(P + e4); mm[u] = cugs_ldnt(M + e4); vv[u] = cugs_ldnt(V + e4);   // streamed: read and written once
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e4 = (int)threadIdx.x + (b + u) * CUGS_BLOCK;
+            if (e4 < total4) {
+                const int r = e4 / ROW4, j = e4 - r * ROW4, ch = j >> 2, k = (j & 3) * 4;
+                const float4 y = *reinterpret_cast<const float4*>(s_fac + r * SH_FACTOR_ROW + k);
+                const float g = s_fac[r * SH_FACTOR_ROW + 16 + ch];
+                adam_update(pp[u].x, k + 0 < num_active ? g * y.x : 0.0f, mm[u].x, vv[u].x, lr, h);
+                adam_update(pp[u].y, k + 1 < num_active ? g * y.y : 0.0f, mm[u].y, vv[u].y, lr, h);
+                adam_update(pp[u].z, k + 2 < num_active ? g * y.z : 0.0f, mm[u].z, vv[u].z, lr, h);
+                adam_update(pp[u].w, k + 3 < num_active ? g * y.w : 0.0f, mm[u].w, vv[u].w, lr, h);
+                cugs_stnt(P + e4, pp[u]); cugs_stnt(M + e4, mm[u]); cugs_stnt(V + e4, vv[u]);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ int active_count(int degree) { return (degree + 1) * (degree + 1); }
 
 
@@ -281,7 +317,7 @@ struct PBPtrs {
 template <int C, bool ALIGNED, bool ADAM, bool FACTORS = false>
 __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int degree, CamArgs cam, PBPtrs p,
                                                                 AdamFusedArgs adam) {
-    static_assert(!FACTORS || (C == 16 && ALIGNED && !ADAM), "factor tile: degree-3 storage, 16-byte rows, plain gradients");
+    static_assert(!FACTORS || (C == 16 && ALIGNED), "factor tile: degree-3 storage, 16-byte rows");
     constexpr int LROW = FACTORS ? SH_FACTOR_ROW : ShTile<C>::LROW;
     __shared__ __attribute__((aligned(16))) float s_sh[CUGS_BLOCK * LROW];
     const int64_t base = (int64_t)blockIdx.x * CUGS_BLOCK;
@@ -313,7 +349,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     if (FACTORS && live) {
         in_radius = p.radii[idx];
         in_scl[0] = ldp(p.scales + idx * 3 + 0); in_scl[1] = ldp(p.scales + idx * 3 + 1); in_scl[2] = ldp(p.scales + idx * 3 + 2);
-        in_q = cugs_ldnt(reinterpret_cast<const float4*>(p.rotations) + idx);
+        in_q = ADAM ? reinterpret_cast<const float4*>(p.rotations)[idx] : cugs_ldnt(reinterpret_cast<const float4*>(p.rotations) + idx);
         in_opa = ldp(p.opacities + idx);
     }
     if (live) {
@@ -345,7 +381,7 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
     if (FACTORS) {
         // kernel-uniform: without dL/dsh (the data-parallel exchange builds it from the gathered colour gradients,
         // cugs_sh_backward_views) nothing goes through the tile
-        if (p.d_sh) {
+        if (ADAM || p.d_sh) {
             if (live) {
                 float4* row = reinterpret_cast<float4*>(s_sh + threadIdx.x * SH_FACTOR_ROW);
                 row[0] = make_float4(Y[0], Y[1], Y[2], Y[3]);
@@ -355,7 +391,8 @@ __global__ __launch_bounds__(CUGS_BLOCK) void k_project_backward(int64_t n, int 
                 row[4] = make_float4(gated[0], gated[1], gated[2], 0.0f);
             }
             __syncthreads();
-            store_sh_rows_from_factors(p.d_sh, base, count, num_active, s_sh);
+            if (ADAM) adam_sh_rows_from_factors(p.w_sh, adam.m[1], adam.v[1], base, count, num_active, s_sh, adam.lr[1], adam);
+            else store_sh_rows_from_factors(p.d_sh, base, count, num_active, s_sh);
         }
     } else if (ADAM || p.d_sh) {                               // kernel-uniform
         if (live) {
@@ -609,6 +646,13 @@ int launch_pb(int64_t n, int degree, const CamArgs& cam, const PBPtrs& p, bool a
               const AdamFusedArgs* adam = nullptr) {
     const AdamFusedArgs none{};
     if (adam) {
+        if constexpr (C == 16) {
+            if (aligned && p.colour_gate) {
+                hipLaunchKernelGGL((k_project_backward<C, true, true, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p, *adam);
+                CUGS_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         if (aligned)
             hipLaunchKernelGGL((k_project_backward<C, true, true>), dim3(grid_for(n)), dim3(CUGS_BLOCK), 0, st, n, degree, cam, p, *adam);
         else
