@@ -745,13 +745,16 @@ def test_compact_exchange_equals_sum_of_views(pkg, orc, dev):
     assert max_err_over_max(np_(pos_sum), np_(full_pos)) <= 1e-5
 
 
-@pytest.mark.parametrize("n,w,h,deg", [(3000, 200, 150, 3), (777, 96, 64, 1), (1000, 128, 96, 0)])
-def test_fused_adam_backward_equals_backward_then_adam(pkg, dev, n, w, h, deg):
+@pytest.mark.parametrize("n,w,h,deg,stored", [(3000, 200, 150, 3, 3), (777, 96, 64, 1, 1), (1000, 128, 96, 0, 0),
+                                              (1301, 128, 96, 1, 3)])
+def test_fused_adam_backward_equals_backward_then_adam(pkg, dev, n, w, h, deg, stored):
     """cugs_project_backward_adam (a8 + a9 + a11 in one launch, single-GPU training): the model, the moments and
     dL_dmeans_2d after render_backward(..., fused_adam=opt) must equal render_backward + apply_gradients + step
     BIT FOR BIT over three steps (moments carried, bias corrections advancing) - same arithmetic, same order;
-    only the blend backward's atomics may reorder sums, so both paths consume the SAME accumulator rows."""
-    arrays, cam = _scene(pkg, n, w, h, deg, seed=n, mu_s=-3.7)
+    only the blend backward's atomics may reorder sums, so both paths consume the SAME accumulator rows.
+    With degree-3 storage both launches keep the FACTORS of the SH gradient rows in LDS; the last case
+    has fewer active coefficients than stored ones and a ragged last workgroup."""
+    arrays, cam = _scene(pkg, n, w, h, stored, seed=n, mu_s=-3.7)
     settings = pkg.RenderSettings(background=[0.2, 0.1, 0.3], active_sh_degree=deg)
     g = torch.from_numpy(pkg.scene.make_dl_dcolor(w, h, seed=n + 1) * 3000.0).to(dev)    # gradients large enough to move parameters
     ma, mb = pkg.scene.to_model(arrays, dev), pkg.scene.to_model(arrays, dev)
